@@ -1,0 +1,296 @@
+/*
+ * rtcore.h — C-ABI of the MI355X-native renderer core (librtcore.so).
+ *
+ * This is the drop-in boundary for the hot path of devinFink/RayTracer: the host
+ * (scene loader, Scene/Camera/Node model, PNG output) stays on the CPU and calls
+ * these entry points instead of the reference's in-process C++ renderer
+ * (`class Renderer` virtuals, reference RayTracer/renderer.h:209-238, implemented by
+ * `class RayTracer`, RayTracer/raytracer.h:14-61).  Plain C, opaque handle, plain
+ * pointers and sizes, int status codes (0 = ok, <0 = error, message via
+ * rt_last_error).  No exceptions cross the boundary, nothing here names torch.
+ *
+ * The same header is the input contract of the CPU oracle (oracle/, test
+ * infrastructure only): both consume one `rt_scene_desc`.
+ *
+ * Conventions
+ *   - All matrices are 3x4, column-major: m[0..2] = column 0, m[3..5] = column 1,
+ *     m[6..8] = column 2, m[9..11] = translation.  (cyMatrix34 cell order as used by
+ *     the reference's Transformation, RayTracer/scene.h:152-192.)
+ *   - Nodes are stored in depth-first order; node 0 is the scene root
+ *     (`Scene::rootNode`, RayTracer/scene.h:484); `parent` < own index.
+ *   - Every pointer inside rt_scene_desc is a HOST pointer owned by the caller;
+ *     rt_scene_commit copies what it needs to the device.
+ */
+#ifndef RTCORE_H_INCLUDED
+#define RTCORE_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)     /* bad argument / inconsistent scene */
+#define RT_ERR_DEVICE (-2)      /* HIP error */
+#define RT_ERR_NOSCENE (-3)     /* call needs a committed scene */
+#define RT_ERR_UNSUPPORTED (-4) /* feature not available in this build */
+#define RT_ERR_OVERFLOW (-5)    /* internal queue capacity exceeded */
+
+/* hit sides — reference RayTracer/scene.h:67-70 */
+#define RT_HIT_NONE 0
+#define RT_HIT_FRONT 1
+#define RT_HIT_BACK 2
+#define RT_HIT_FRONT_AND_BACK 3
+
+/* ------------------------------------------------------------------ scene */
+typedef struct rt_mat34 { float m[12]; } rt_mat34;
+
+enum { RT_PRIM_NONE = 0, RT_PRIM_SPHERE = 1, RT_PRIM_PLANE = 2, RT_PRIM_MESH = 3 };
+
+/* One scene-graph node (reference `class Node`, RayTracer/scene.h:401-441). */
+typedef struct rt_node {
+  int32_t parent;      /* -1 for the root */
+  int32_t prim_kind;   /* RT_PRIM_* : theSphere / thePlane / TriObj (xmlload.cpp:143-161) */
+  int32_t mesh_id;     /* index into rt_scene_desc.meshes when prim_kind == RT_PRIM_MESH */
+  int32_t material_id; /* index into materials, -1 = none (default Blinn is substituted) */
+  rt_mat34 tm;         /* local -> parent   (Transformation::tm,  scene.h:155) */
+  rt_mat34 itm;        /* parent -> local   (Transformation::itm, scene.h:156) */
+} rt_node;
+
+/* 2-wide BVH node over one mesh, 32 bytes (stand-in for cyBVH's node: 6-float box +
+ * child/leaf word; reference use: RayTracer/objects.cpp:268-371).
+ * Internal node: a = left child index, b = right child index.
+ * Leaf node:     a = first index into bvh_elements, b = 0x80000000u | element count (1..4). */
+typedef struct rt_bvh_node {
+  float bmin[3];
+  uint32_t a;
+  float bmax[3];
+  uint32_t b;
+} rt_bvh_node;
+#define RT_BVH_LEAF_BIT 0x80000000u
+
+/* Triangle mesh (reference `class TriObj : Object, cyTriMesh`, RayTracer/objects.h:52-75). */
+typedef struct rt_mesh {
+  const float* positions;   /* 3 floats per vertex            (cyTriMesh::V)  */
+  const float* normals;     /* 3 floats per normal            (cyTriMesh::VN) */
+  const float* uvw;         /* 3 floats per texture vertex    (cyTriMesh::VT) */
+  const uint32_t* pos_idx;  /* 3 per face                     (cyTriMesh::F)  */
+  const uint32_t* nrm_idx;  /* 3 per face                     (cyTriMesh::FN) */
+  const uint32_t* uvw_idx;  /* 3 per face, may be NULL => uvw (0,0,0)  (cyTriMesh::FT) */
+  uint32_t n_positions, n_normals, n_uvw, n_faces;
+  const rt_bvh_node* bvh;   /* node 0 = root                  (BVHTriMesh, objects.h:65) */
+  const uint32_t* bvh_elements; /* face ids, grouped per leaf */
+  uint32_t n_bvh_nodes, n_bvh_elements;
+  float bound_min[3], bound_max[3]; /* cyTriMesh::GetBoundMin/Max (objects.h:57) */
+} rt_mesh;
+
+/* TexturedValue<Color> / TexturedValue<float> (RayTracer/scene.h:356-397) */
+typedef struct rt_tex_color { float value[3]; int32_t map; } rt_tex_color; /* map: index into texmaps, -1 = none */
+typedef struct rt_tex_float { float value; int32_t map; } rt_tex_float;
+
+enum { RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 };
+/* TextureMap = Transformation + Texture* (RayTracer/scene.h:330-349) */
+typedef struct rt_texmap {
+  int32_t kind;          /* RT_TEX_CHECKER (texture.cpp:136-140) or RT_TEX_IMAGE (texture.cpp:106-132) */
+  int32_t image;         /* index into images (RT_TEX_IMAGE) */
+  rt_mat34 itm;          /* uvw -> texture space (TextureMap::Eval uses TransformTo, scene.h:337) */
+  rt_tex_color color[2]; /* checker colours; may themselves be textured (xmlload.cpp:370-374) */
+} rt_texmap;
+
+typedef struct rt_image { const uint8_t* rgb; int32_t width, height; } rt_image; /* RGB8, row 0 first */
+
+enum { RT_MTL_BLINN = 1, RT_MTL_WHITE = 2 /* MtlPhong / MtlMicrofacet stubs return white, materials.cpp:392-408 */ };
+/* MtlBasePhongBlinn fields (RayTracer/materials.h:52-60) */
+typedef struct rt_material {
+  int32_t kind;
+  rt_tex_color diffuse, specular, emission, reflection, refraction;
+  rt_tex_float glossiness;
+  float absorption[3];
+  float ior;
+} rt_material;
+
+enum { RT_LIGHT_AMBIENT = 1, RT_LIGHT_DIRECT = 2, RT_LIGHT_POINT = 3 };
+/* AmbientLight / DirectLight / PointLight (RayTracer/lights.h:28-77) */
+typedef struct rt_light {
+  int32_t kind;
+  float intensity[3];
+  float position[3];  /* point */
+  float direction[3]; /* direct, normalised by the loader (xmlload.cpp:232) */
+  float size;         /* point: sphere-light radius; 0 = hard shadows */
+  float attenuation;  /* point: non-zero => 1/d^2 (lights.cpp:68-71) */
+} rt_light;
+
+/* Camera (RayTracer/scene.h:445-467), already post-processed as Camera::Load does
+ * (dir = normalise(target-pos), up re-orthogonalised; xmlload.cpp:105-121). */
+typedef struct rt_camera {
+  float pos[3], dir[3], up[3];
+  float fov, focaldist, dof;
+  int32_t width, height;
+  int32_t srgb;
+} rt_camera;
+
+typedef struct rt_scene_desc {
+  const rt_node* nodes;         uint32_t n_nodes;
+  const rt_mesh* meshes;        uint32_t n_meshes;
+  const rt_material* materials; uint32_t n_materials;
+  const rt_texmap* texmaps;     uint32_t n_texmaps;
+  const rt_image* images;       uint32_t n_images;
+  const rt_light* lights;       uint32_t n_lights;
+  rt_tex_color background;      /* Scene::background  (scene.h:489) */
+  rt_tex_color environment;     /* Scene::environment (scene.h:490) */
+  rt_camera camera;
+} rt_scene_desc;
+
+/* ------------------------------------------------------------- rays / hits */
+/* Ray (RayTracer/scene.h:55-63); invDir is derived inside. */
+typedef struct rt_ray { float p[3]; float dir[3]; } rt_ray;
+
+/* HitInfo (RayTracer/scene.h:74-90) in world space, before SamplerInfo::SetHit. */
+typedef struct rt_hit {
+  float p[3];
+  float z;        /* ray parameter of the hit; FLT_MAX on miss */
+  float N[3];     /* un-normalised shading normal in world space */
+  float uvw[3];
+  int32_t node;   /* node index of the hit object, -1 on miss or light */
+  int32_t face;   /* face id for meshes, else -1 */
+  int32_t light;  /* index of the renderable light that was hit, else -1 */
+  int32_t front;  /* 1 front / 0 back */
+} rt_hit;
+
+/* ---------------------------------------------------------- render params */
+enum { RT_SAMPLER_PHILOX = 0, RT_SAMPLER_PCG_HALTON = 1 /* CPU oracle only */ };
+
+/* Every compile-time constant of the reference renderer as data
+ * (raytracer.h:17-23,46; renderer.h:172-174; RayTracer.cpp:191; materials.cpp:316,320). */
+typedef struct rt_render_params {
+  int32_t width, height;      /* 0 = use the camera's */
+  int32_t sampler;            /* RT_SAMPLER_* */
+  uint32_t seed_lo, seed_hi;  /* Philox key */
+  int32_t spp_min, spp_max;   /* reference 32 / 128; equal => fixed spp, no adaptive stop */
+  int32_t sample_begin;       /* first camera-sample index rendered by this call (multi-GPU sample split) */
+  int32_t sample_count;       /* number of samples rendered by this call; 0 = spp_max - sample_begin */
+  float adaptive_threshold;   /* 0.01 */
+  int32_t pixel_jitter;       /* 1 = Halton jitter + lens sampling (reference), 0 = pixel centre, no DOF */
+  int32_t max_bounces;        /* bounceCount = 3 */
+  int32_t mc_bounces;         /* monteCarloBounces; 0 = indirect-diffuse sampler off */
+  int32_t mc_samples;         /* mcSamples = 1 */
+  int32_t shadow_min, shadow_max; /* 16 / 128 */
+  float light_size_scale;     /* multiplies every point light's size for shadowing; 0 => one ray to the centre */
+  int32_t dedup_hard_shadows; /* 1: a size-0 light fires one shadow ray instead of 16/128 identical ones */
+  int32_t photons;            /* 0 = photon term off, 1 = on */
+  int32_t n_photons;          /* numPhotons = 100000 per map */
+  float photon_radius;        /* 3.0 */
+  int32_t photon_k;           /* 128 */
+  float ellipticity_global;   /* 1.0 */
+  float ellipticity_caustic;  /* 0.25 */
+  int32_t skip_zero_weight;   /* 1: do not trace secondary rays whose contribution is multiplied by zero (result-identical) */
+  int32_t tile_begin, tile_count, tile_stride; /* tile split: render 32x32 tiles t = tile_begin + k*tile_stride; tile_count 0 = all */
+  int32_t photon_emit_limit;  /* stop emitting after this many photons even if a map is not full (the reference loops
+                                 forever then, RayTracer.cpp:277); 0 = 20 * n_photons */
+  int32_t photon_max_bounces; /* cap on the photon random walk (the reference has none, RayTracer.cpp:325); 0 = 64 */
+  int32_t reserved[2];
+} rt_render_params;
+
+/* Output images.  Any pointer may be NULL.  Host memory unless `on_device` != 0. */
+typedef struct rt_framebuffer {
+  uint8_t* rgb8;          /* W*H*3, Color24 image (RenderImage::img, renderer.h:38) */
+  float* radiance;        /* W*H*4: mean linear r,g,b and sample count */
+  int32_t* sample_count;  /* W*H      (RenderImage::sampleCount, renderer.h:41) */
+  int32_t* hit_node;      /* W*H: node index hit by the first camera sample's primary ray, -1 miss, -2-l light l */
+  int32_t* hit_face;      /* W*H: face id for mesh hits, else -1 */
+  int32_t on_device;
+  int32_t reserved;
+} rt_framebuffer;
+
+/* Algorithmic work counters. */
+typedef struct rt_counters {
+  uint64_t rays_primary, rays_secondary, rays_shadow, rays_photon;
+  uint64_t inst_tests, sphere_tests, plane_tests, node_visits, tri_tests;
+  uint64_t shades, tex_evals, photon_visits, gathers;
+  uint64_t paths;
+} rt_counters;
+
+enum { RT_K_RAYGEN = 0, RT_K_TRACE_CLOSEST, RT_K_SHADE, RT_K_SHADOW, RT_K_ACCUM, RT_K_PHOTON_TRACE, RT_K_PHOTON_GATHER, RT_K_DENOISE, RT_K_COUNT };
+/* HIP-event timing of the library's own kernels on its own stream. */
+typedef struct rt_profile {
+  double ms[RT_K_COUNT];
+  uint64_t launches[RT_K_COUNT];
+  uint64_t items[RT_K_COUNT]; /* rays / shade points / pixels processed */
+} rt_profile;
+
+/* 32-byte photon record, layout-compatible with PhotonMap::PhotonData (photonmap.h:42-49). */
+typedef struct rt_photon {
+  float position[3];
+  float power;
+  float dir[3];
+  uint8_t color[3];
+  uint8_t plane;
+} rt_photon;
+
+typedef struct rt_context rt_context;
+
+/* ------------------------------------------------------------ entry points */
+
+/* Replaces `new RayTracer` (RayTracer/main.cpp:11).  One context drives one GPU. */
+int rt_context_create(int device_id, rt_context** out);
+void rt_context_destroy(rt_context* ctx);
+const char* rt_last_error(const rt_context* ctx);
+
+/* Replaces the in-memory hand-over at the end of Renderer::LoadScene (xmlload.cpp:70-72):
+ * the flattened scene is copied to the device, instance chains and acceleration data are built. */
+int rt_scene_commit(rt_context* ctx, const rt_scene_desc* scene);
+
+/* Batched Renderer::TraceRay (RayTracer.cpp:336-339 -> TraverseTree :373-435). Host pointers. */
+int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits);
+/* Batched Renderer::TraceShadowRay (RayTracer.cpp:341-344 -> TraverseTreeShadow :346-371). Host pointers. */
+int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded);
+
+/* Replaces BeginRender + the wait in StopRender (RayTracer.cpp:24-58), blocking:
+ * photon pass (if enabled), per-pixel sampling loop, resolve (mean, sRGB, Color24). */
+int rt_render(rt_context* ctx, const rt_render_params* params, rt_framebuffer* fb);
+
+/* Asynchronous form mirroring BeginRender ("returns immediately", renderer.h:229), the
+ * viewport's polling of GetNumRenderedPixels (viewport.cpp:583-586) and StopRender
+ * ("should wait till rendering threads stop", renderer.h:230). */
+int rt_render_begin(rt_context* ctx, const rt_render_params* params, rt_framebuffer* fb);
+int rt_render_poll(rt_context* ctx, int64_t* pixels_done, int* finished);
+int rt_render_wait(rt_context* ctx);
+
+/* Multi-GPU form: add this call's samples into a DEVICE accumulator of W*H*8 floats
+ * (sum r,g,b, n, sum r^2,g^2,b^2, unused) that the caller owns (e.g. a torch tensor) and may
+ * all-reduce over RCCL before rt_resolve.  The per-pixel loop of RunThread (RayTracer.cpp:117-204)
+ * without its final division. */
+int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, void* d_accum);
+/* Final division, sRGB, Color24 (RayTracer.cpp:206-216) from a device accumulator. */
+int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_accum, rt_framebuffer* fb);
+
+/* GeneratePhotons (RayTracer.cpp:262-294): emission, random walk, both maps, balance. */
+int rt_photons_build(rt_context* ctx, const rt_render_params* params);
+/* GetPhotonMap / GetCausticsMap (raytracer.h:41-42): which = 0 global, 1 caustics. */
+int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n);
+/* Batched PhotonMap::EstimateIrradiance<k> (photonmap.h:98-99,268-309). Host pointers, 3 floats each. */
+int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N, size_t n,
+                     float radius, float ellipticity, int k, float* irradiance);
+
+/* Denoiser::Denoise(Color*,Color*) (RayTracer/denoiser.cpp:22-64).  rgb_in/out: W*H*3 floats, host.
+ * albedo/normal (W*H*3 each) may be NULL (the reference declares that overload, denoiser.h:16-17). */
+int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t width, int32_t height,
+               const float* albedo, const float* normal);
+
+int rt_counters_enable(rt_context* ctx, int enable); /* counted builds of the kernels; off by default */
+int rt_counters_reset(rt_context* ctx);
+int rt_counters_get(rt_context* ctx, rt_counters* out);
+int rt_profile_enable(rt_context* ctx, int enable);
+int rt_profile_reset(rt_context* ctx);
+int rt_profile_get(rt_context* ctx, rt_profile* out);
+
+/* Fills params with the reference's defaults (raytracer.h:17-23, renderer.h:172-174). */
+void rt_render_params_default(rt_render_params* params);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

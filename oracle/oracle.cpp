@@ -1,0 +1,1745 @@
+// oracle.cpp — CPU restatement of the reference renderer's hot path.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle.h).  Nothing under raytracer_amd/ links or calls this file.
+//
+// Every routine cites the reference file:line it follows (paths relative to
+// /root/reference/RayTracer/).  Where the reference has undefined behaviour the position taken is
+// the one recorded in SURVEY.md §3.6 (Q1..Q18) and repeated at the site.
+//
+// Pinning status (DESIGN.md "Oracle"):
+//   * PCG32 / Halton: pinned against the reference's own rng.h compiled unmodified (oracle/_ref)
+//     and the published PCG32 known-answer vector.
+//   * Philox4x32-10: pinned against the Random123 known-answer vectors.
+//   * Everything that goes through cyCodeBase (GetOrthonormals, Color24 rounding, Linear2sRGB,
+//     matrix inverse, BVH topology) and OIDN: the headers are absent from the reference checkout
+//     and it holds no tests -> PARITY UNPINNED for those; the definitions used here are this
+//     build's own and are shared (as definitions, not code) with the HIP kernels.
+//
+// Compile with -ffp-contract=off: the HIP kernels are built the same way so that intersection
+// decisions agree bit for bit.
+#include "oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+constexpr float BIGFLOAT = FLT_MAX;  // scene.h:34
+
+// ---------------------------------------------------------------- vectors
+struct V {
+  float x, y, z;
+  V() : x(0), y(0), z(0) {}
+  V(float a, float b, float c) : x(a), y(b), z(c) {}
+  float operator[](int i) const { return (&x)[i]; }
+  float& operator[](int i) { return (&x)[i]; }
+};
+inline V operator+(V a, V b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V operator-(V a, V b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V operator-(V a) { return V(-a.x, -a.y, -a.z); }
+inline V operator*(V a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+inline V operator*(float s, V a) { return V(a.x * s, a.y * s, a.z * s); }
+inline V operator*(V a, V b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V operator/(V a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+inline float dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V cross(V a, V b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline float length(V a) { return sqrtf(dot(a, a)); }
+inline V normalized(V a) { return a / length(a); }
+inline V from3(const float* p) { return V(p[0], p[1], p[2]); }
+typedef V Color;
+
+// 3x4 column-major (rtcore.h conventions)
+inline V xform_point(const rt_mat34& m, V p) {
+  return V(m.m[0] * p.x + m.m[3] * p.y + m.m[6] * p.z + m.m[9], m.m[1] * p.x + m.m[4] * p.y + m.m[7] * p.z + m.m[10],
+           m.m[2] * p.x + m.m[5] * p.y + m.m[8] * p.z + m.m[11]);
+}
+inline V xform_dir(const rt_mat34& m, V p) {
+  return V(m.m[0] * p.x + m.m[3] * p.y + m.m[6] * p.z, m.m[1] * p.x + m.m[4] * p.y + m.m[7] * p.z,
+           m.m[2] * p.x + m.m[5] * p.y + m.m[8] * p.z);
+}
+// (3x3 block)^T * v   — Matrix3::TransposeMult as used by NormalTransformFrom (scene.h:180)
+inline V xform_tmul(const rt_mat34& m, V p) {
+  return V(m.m[0] * p.x + m.m[1] * p.y + m.m[2] * p.z, m.m[3] * p.x + m.m[4] * p.y + m.m[5] * p.z,
+           m.m[6] * p.x + m.m[7] * p.y + m.m[8] * p.z);
+}
+
+// cyVec3::GetOrthonormals as this build defines it (cyVector.h absent).  n is unit length.
+inline void orthonormals(V n, V& v0, V& v1) {
+  if (n.z >= n.y) {
+    float a = 1.0f / (1.0f + n.z);
+    float b = -n.x * n.y * a;
+    v0 = V(1.0f - n.x * n.x * a, b, -n.x);
+    v1 = V(b, 1.0f - n.y * n.y * a, -n.y);
+  } else {
+    float a = 1.0f / (1.0f + n.y);
+    float b = -n.z * n.x * a;
+    v0 = V(b, -n.z, 1.0f - n.z * n.z * a);
+    v1 = V(1.0f - n.x * n.x * a, -n.x, b);
+  }
+}
+
+// Color24(Color) channel conversion and its inverse, as this build defines them (cyColor.h absent).
+inline uint8_t to_byte(float v) {
+  if (!(v == v)) return 0;
+  float s = v * 255.0f + 0.5f;
+  if (s <= 0.0f) return 0;
+  if (s >= 255.0f) return 255;
+  return (uint8_t)(int)s;
+}
+inline float linear_to_srgb(float v) {
+  return v < 0.0031308f ? v * 12.92f : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+}
+
+// ---------------------------------------------------------------- rng.h restated
+struct PCG {  // rng.h:29-99
+  uint64_t state, inc;
+  static uint64_t mix(uint64_t v) {  // rng.h:90-98
+    v ^= (v >> 31);
+    v *= 0x7fb5d329728ea185ULL;
+    v ^= (v >> 27);
+    v *= 0x81dadef4bc2dd44dULL;
+    v ^= (v >> 33);
+    return v;
+  }
+  void set(uint64_t seq, uint64_t seed) {  // rng.h:39-46
+    state = 0u;
+    inc = (seq << 1u) | 1u;
+    next();
+    state += seed;
+    next();
+  }
+  explicit PCG(uint64_t seq = 0) { set(seq, mix(seq)); }  // rng.h:34,38
+  uint32_t next() {                                       // rng.h:49-57
+    uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+  }
+  float f() {  // rng.h:60-65
+    const float rmax = 0x1.fffffep-1f;
+    float r = next() * 0x1p-32f;
+    return r < rmax ? r : rmax;
+  }
+};
+
+inline float halton(int index, int base) {  // rng.h:103-112
+  float r = 0;
+  float f = 1.0f / (float)base;
+  for (int i = index; i > 0; i /= base) {
+    r += f * (i % base);
+    f /= (float)base;
+  }
+  return r;
+}
+
+// Philox4x32-10 (Salmon et al., Random123) — replaces the reference's non-reproducible seeding.
+inline void philox(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[4]) {
+  uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3];
+  uint32_t k0 = k_in[0], k1 = k_in[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+inline float u32_to_unit(uint32_t u) {  // same mapping as RNG::RandomFloat (rng.h:60-65)
+  const float rmax = 0x1.fffffep-1f;
+  float r = u * 0x1p-32f;
+  return r < rmax ? r : rmax;
+}
+
+// Philox stream tags
+enum { TAG_PIXEL = 0, TAG_SHADE = 1, TAG_PHOTON = 2 };
+
+// ---------------------------------------------------------------- rays, hits
+struct Ray {  // scene.h:55-63
+  V p, dir, inv;
+  Ray() {}
+  Ray(V p_, V d_) : p(p_), dir(d_) { inv = V(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); }
+};
+
+struct Hit {  // scene.h:74-90
+  V p;
+  float z;
+  int node;
+  V N;
+  V uvw;
+  bool front;
+  int light;  // -1, or index of the renderable light hit (the reference keeps a bool)
+  int face;
+  Hit() { init(); }
+  void init() {
+    z = BIGFLOAT; node = -1; uvw = V(0.5f, 0.5f, 0.5f); front = true; light = -1; face = -1;
+    p = V(); N = V();
+  }
+};
+
+struct Counters {
+  uint64_t rays_primary = 0, rays_secondary = 0, rays_shadow = 0, rays_photon = 0;
+  uint64_t inst_tests = 0, sphere_tests = 0, plane_tests = 0, node_visits = 0, tri_tests = 0;
+  uint64_t shades = 0, tex_evals = 0, photon_visits = 0, gathers = 0, paths = 0;
+  void add(const Counters& o) {
+    rays_primary += o.rays_primary; rays_secondary += o.rays_secondary; rays_shadow += o.rays_shadow;
+    rays_photon += o.rays_photon; inst_tests += o.inst_tests; sphere_tests += o.sphere_tests;
+    plane_tests += o.plane_tests; node_visits += o.node_visits; tri_tests += o.tri_tests; shades += o.shades;
+    tex_evals += o.tex_evals; photon_visits += o.photon_visits; gathers += o.gathers; paths += o.paths;
+  }
+  void store(rt_counters* c) const {
+    if (!c) return;
+    c->rays_primary = rays_primary; c->rays_secondary = rays_secondary; c->rays_shadow = rays_shadow;
+    c->rays_photon = rays_photon; c->inst_tests = inst_tests; c->sphere_tests = sphere_tests;
+    c->plane_tests = plane_tests; c->node_visits = node_visits; c->tri_tests = tri_tests; c->shades = shades;
+    c->tex_evals = tex_evals; c->photon_visits = photon_visits; c->gathers = gathers; c->paths = paths;
+  }
+};
+
+// ---------------------------------------------------------------- photon map (photonmap.h restated)
+struct PhotonMapO {
+  std::vector<rt_photon> photons;  // 1-based, slot 0 unused (photonmap.h:65)
+  int stored = 0;
+  int half_stored = 0;
+  bool balanced = false;
+
+  void resize(int n) { photons.assign((size_t)n + 1, rt_photon{}); stored = 0; balanced = false; }
+  int size() const { return (int)photons.size() - 1; }
+  int remaining() const { return (int)photons.size() - stored - 1; }
+
+  // PhotonData::SetPower (photonmap.h:148-154)
+  static void set_power(rt_photon& p, Color c) {
+    float power = c.x;
+    if (power < c.y) power = c.y;
+    if (power < c.z) power = c.z;
+    p.power = power;
+    p.color[0] = to_byte(c.x / power);
+    p.color[1] = to_byte(c.y / power);
+    p.color[2] = to_byte(c.z / power);
+  }
+  static Color get_power(const rt_photon& p) {  // photonmap.h:55 (Color24::ToColor = /255)
+    return Color(p.color[0] / 255.0f, p.color[1] / 255.0f, p.color[2] / 255.0f) * p.power;
+  }
+  bool add(V pos, V dir, Color power) {  // photonmap.h:158-172
+    if (stored >= size()) return false;
+    int i = ++stored;
+    rt_photon p{};
+    p.position[0] = pos.x; p.position[1] = pos.y; p.position[2] = pos.z;
+    p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
+    set_power(p, power);
+    photons[i] = p;
+    return true;
+  }
+  void scale(float s) {  // photonmap.h:82
+    for (int i = 1; i <= stored; i++) photons[i].power *= s;
+  }
+  void swap_ph(int i, int j) { std::swap(photons[i], photons[j]); }
+
+  void balance_segment(std::vector<rt_photon>& bal, V bmin, V bmax, int index, int start, int end) {  // photonmap.h:202-264
+    int median = 1;
+    while ((4 * median) <= (end - start + 1)) median += median;
+    if ((3 * median) <= (end - start + 1)) {
+      median += median;
+      median += start - 1;
+    } else {
+      median = end - median + 1;
+    }
+    int axis = 2;
+    V d = bmax - bmin;
+    if (d.x > d.y) {
+      if (d.x > d.z) axis = 0;
+    } else if (d.y > d.z) axis = 1;
+    int left = start, right = end;
+    while (right > left) {
+      float const v = photons[right].position[axis];
+      int i = left - 1;
+      int j = right;
+      while (photons[++i].position[axis] < v) {}
+      while (photons[--j].position[axis] > v && j > left) {}
+      while (i < j) {
+        swap_ph(i, j);
+        while (photons[++i].position[axis] < v) {}
+        while (photons[--j].position[axis] > v && j > left) {}
+      }
+      swap_ph(i, right);
+      if (i >= median) right = i - 1;
+      if (i <= median) left = i + 1;
+    }
+    bal[index] = photons[median];
+    bal[index].plane = (uint8_t)((bal[index].plane & 0x8) | (axis & 0x3));
+    if (median > start) {
+      if (start < median - 1) {
+        V tmax = bmax;
+        tmax[axis] = bal[index].position[axis];
+        balance_segment(bal, bmin, tmax, 2 * index, start, median - 1);
+      } else {
+        bal[2 * index] = photons[start];
+      }
+    }
+    if (median < end) {
+      if (median + 1 < end) {
+        V tmin = bmin;
+        tmin[axis] = bal[index].position[axis];
+        balance_segment(bal, tmin, bmax, 2 * index + 1, median + 1, end);
+      } else {
+        bal[2 * index + 1] = photons[end];
+      }
+    }
+  }
+  void prepare() {  // photonmap.h:176-198
+    balanced = true;
+    half_stored = stored / 2 - 1;
+    if (photons.empty() || stored == 0) return;
+    V bmin = from3(photons[0].position), bmax = bmin;  // slot 0 is zero-initialised
+    for (int i = 1; i <= stored; i++) {
+      V p = from3(photons[i].position);
+      if (bmin.x > p.x) bmin.x = p.x;
+      if (bmax.x < p.x) bmax.x = p.x;
+      if (bmin.y > p.y) bmin.y = p.y;
+      if (bmax.y < p.y) bmax.y = p.y;
+      if (bmin.z > p.z) bmin.z = p.z;
+      if (bmax.z < p.z) bmax.z = p.z;
+    }
+    // the reference sizes balancedMap stored+1 and writes index 2*index+1 <= stored; keep one spare slot
+    std::vector<rt_photon> bal((size_t)stored + 2);
+    balance_segment(bal, bmin, bmax, 1, 1, stored);
+    bal.resize(photons.size() > bal.size() ? photons.size() : bal.size());
+    photons.swap(bal);
+  }
+
+  struct Nearest {
+    V pos, normal;
+    float norm_scale;
+    int max_photons, found;
+    float* dist2;
+    int* idx;
+  };
+  // photonmap.h:339-414 (useNormal = true); photon copies are kept as indices
+  void locate(Nearest& np, int index, Counters* cnt) const {
+    const rt_photon& p = photons[index];
+    if (cnt) cnt->photon_visits++;
+    int axis = p.plane & 0x3;
+    if (index < half_stored) {
+      float dist = np.pos[axis] - p.position[axis];
+      if (dist > 0) {
+        locate(np, 2 * index + 1, cnt);
+        if (dist * dist < np.dist2[0]) locate(np, 2 * index, cnt);
+      } else {
+        locate(np, 2 * index, cnt);
+        if (dist * dist < np.dist2[0]) locate(np, 2 * index + 1, cnt);
+      }
+    }
+    V dif = from3(p.position) - np.pos;
+    float dist2 = dot(dif, dif);
+    if (dist2 < np.dist2[0]) {
+      V dir = from3(p.dir);
+      if (dot(dir, np.normal) >= 0) return;
+      if (np.norm_scale > 0) {
+        float perp = dot(dif, np.normal);
+        dif = dif + np.normal * (perp * np.norm_scale);
+        dist2 = dot(dif, dif);
+        if (dist2 >= np.dist2[0]) return;
+      }
+      if (np.found < np.max_photons) {
+        np.found++;
+        np.dist2[np.found] = dist2;
+        np.idx[np.found] = index;
+        if (np.found == np.max_photons) {
+          int half_found = np.found >> 1;
+          for (int k = half_found; k >= 1; k--) {
+            int parent = k;
+            int tp = np.idx[k];
+            float td2 = np.dist2[k];
+            while (parent <= half_found) {
+              int j = parent + parent;
+              if (j < np.found && np.dist2[j] < np.dist2[j + 1]) j++;
+              if (td2 >= np.dist2[j]) break;
+              np.dist2[parent] = np.dist2[j];
+              np.idx[parent] = np.idx[j];
+              parent = j;
+            }
+            np.idx[parent] = tp;
+            np.dist2[parent] = td2;
+          }
+        }
+      } else {
+        int parent = 1;
+        int j = 2;
+        while (j <= np.found) {
+          if (j < np.found && np.dist2[j] < np.dist2[j + 1]) j++;
+          if (dist2 > np.dist2[j]) break;
+          np.dist2[parent] = np.dist2[j];
+          np.idx[parent] = np.idx[j];
+          parent = j;
+          j <<= 1;
+        }
+        np.idx[parent] = index;
+        np.dist2[parent] = dist2;
+        np.dist2[0] = np.dist2[1];
+      }
+    }
+  }
+  // photonmap.h:268-309, constant filter, with normal
+  Color estimate(V pos, V normal, float radius, float ellipticity, int k, Counters* cnt) const {
+    Color irrad(0, 0, 0);
+    if (stored == 0 || !balanced) return irrad;
+    if (cnt) cnt->gathers++;
+    std::vector<float> d2((size_t)k + 1);
+    std::vector<int> ix((size_t)k + 1);
+    Nearest np;
+    np.pos = pos;
+    np.normal = normal;
+    np.norm_scale = ellipticity == 1 ? 0 : 1 / ellipticity - 1;
+    np.max_photons = k;
+    np.found = 0;
+    np.dist2 = d2.data();
+    np.idx = ix.data();
+    np.dist2[0] = radius * radius;
+    locate(np, 1, cnt);
+    for (int i = 1; i <= np.found; i++) irrad = irrad + get_power(photons[np.idx[i]]);
+    if (np.found > 0) {
+      float area = (float)M_PI * np.dist2[0];
+      if (area > 0) {
+        float const one_over_area = 1.0f / area;
+        irrad = irrad * one_over_area;
+      }
+    }
+    return irrad;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------- scene wrapper
+struct orc_scene {
+  rt_scene_desc d;
+  std::vector<std::vector<int>> children;
+  std::vector<float> h2, h3, h5, h7;  // HaltonSeq<128> tables (RayTracer.cpp:125-128, lights.cpp:23-24)
+  std::vector<float> hphi, htheta;    // HaltonSeq<1000> (shadowInfo.h:9-10)
+  PhotonMapO pmap, cmap;
+  std::vector<rt_photon> pmap_raw, cmap_raw;  // insertion order, scaled
+  bool photons_built = false;
+  rt_material default_mtl;
+};
+
+namespace {
+
+const rt_material& node_material(const orc_scene& S, int node) {
+  int m = S.d.nodes[node].material_id;
+  if (m < 0 || m >= (int)S.d.n_materials) return S.default_mtl;
+  return S.d.materials[m];
+}
+
+// ---------------------------------------------------------------- primitives (objects.cpp restated)
+
+// Sphere::IntersectRay — objects.cpp:20-61
+bool sphere_intersect(const Ray& ray, Hit& h, int hitSide) {
+  constexpr int r = 1;
+  constexpr float eps = 0.002f;
+  float a = dot(ray.dir, ray.dir);
+  float b = (float)(2.0 * (double)dot(ray.dir, ray.p - V(0, 0, 0)));
+  float c = dot(ray.p, ray.p) - r * r;
+  float discriminant = b * b - 4 * a * c;
+  if (discriminant < 0) return false;
+  float sqrt_disc = sqrtf(discriminant);
+  float twoA = 2 * a;
+  float t1 = (-b - sqrt_disc) / (twoA);
+  float t2 = (-b + sqrt_disc) / (twoA);
+  auto fill = [&](float t, bool front) {
+    h.z = t;
+    h.p = ray.p + (ray.dir * t);
+    h.N = normalized(h.p);
+    float tu = (float)((atan2f(h.p.y, h.p.x) / (2 * M_PI)) + .5);
+    float tv = (float)(asinf(h.p.z) / M_PI + .5);
+    h.uvw = V(tu, tv, 0.0f);
+    h.front = front;
+  };
+  if (t1 > eps && (hitSide & RT_HIT_FRONT)) {
+    if (h.z > t1) { fill(t1, true); return true; }
+  } else if (t2 >= eps && (hitSide & RT_HIT_BACK)) {
+    if (h.z > t2) { fill(t2, false); return true; }
+  }
+  return false;
+}
+
+// Sphere::ShadowRay — objects.cpp:63-82
+bool sphere_shadow(const Ray& ray, float t_max) {
+  constexpr int r = 1;
+  float a = dot(ray.dir, ray.dir);
+  float b = (float)(2.0 * (double)dot(ray.dir, ray.p - V(0, 0, 0)));
+  float c = dot(ray.p, ray.p) - r * r;
+  float discriminant = b * b - 4 * a * c;
+  if (discriminant < 0) return false;
+  float sqrt_disc = sqrtf(discriminant);
+  float twoA = 2 * a;
+  float t1 = (-b - sqrt_disc) / (twoA);
+  float t2 = (-b + sqrt_disc) / (twoA);
+  if ((double)t1 > 0.01 && t1 < t_max) return true;
+  if ((double)t2 > 0.01 && t2 < t_max) return true;
+  return false;
+}
+
+// Plane::IntersectRay — objects.cpp:126-150
+bool plane_intersect(const Ray& ray, Hit& h, int hitSide) {
+  V planeNorm(0.0f, 0.0f, 1.0f);
+  if (fabsf(ray.dir.z) < 1e-8f) return false;
+  float t = -(ray.p.z / ray.dir.z);
+  if ((double)t > 0.0002 && h.z > t) {
+    h.z = t;
+    h.N = planeNorm;
+    h.p = ray.p + (ray.dir * t);
+    h.uvw = V((h.p.x + 1.0f) * 0.5f, (h.p.y + 1.0f) * 0.5f, 0.0f);
+    if (h.p.x < -1.0f || h.p.x > 1.0f || h.p.y < -1.0f || h.p.y > 1.0f) return false;
+    h.front = (dot(ray.dir, planeNorm) < 0);
+    if ((h.front && (hitSide & RT_HIT_FRONT)) || (!h.front && (hitSide & RT_HIT_BACK))) return true;
+  }
+  return false;
+}
+
+// Plane::ShadowRay — objects.cpp:152-167 (no parallel-ray guard)
+bool plane_shadow(const Ray& ray, float t_max) {
+  float t = -(ray.p.z / ray.dir.z);
+  if ((double)t > 0.0002 && t < t_max) {
+    V p = ray.p + (ray.dir * t);
+    if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f) return false;
+    return true;
+  }
+  return false;
+}
+
+// hitAABB — objects.cpp:94-120
+#define FAST_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define FAST_MAX(a, b) ((a) > (b) ? (a) : (b))
+bool hit_aabb(const Ray& ray, const float* b) {
+  float b0 = b[0], b1 = b[1], b2 = b[2];
+  float b3 = b[3], b4 = b[4], b5 = b[5];
+  float t1 = (b0 - ray.p.x) * ray.inv.x;
+  float t2 = (b3 - ray.p.x) * ray.inv.x;
+  float t3 = (b1 - ray.p.y) * ray.inv.y;
+  float t4 = (b4 - ray.p.y) * ray.inv.y;
+  float t5 = (b2 - ray.p.z) * ray.inv.z;
+  float t6 = (b5 - ray.p.z) * ray.inv.z;
+  float tminX = FAST_MIN(t1, t2);
+  float tmaxX = FAST_MAX(t1, t2);
+  float tminY = FAST_MIN(t3, t4);
+  float tmaxY = FAST_MAX(t3, t4);
+  float tminZ = FAST_MIN(t5, t6);
+  float tmaxZ = FAST_MAX(t5, t6);
+  float tmin = FAST_MAX(FAST_MAX(tminX, tminY), tminZ);
+  float tmax = FAST_MIN(FAST_MIN(tmaxX, tmaxY), tmaxZ);
+  return tmax >= tmin && tmax >= 0.0f;
+}
+
+// TriObj::IntersectTriangle — objects.cpp:193-231 (hitSide is ignored there)
+bool tri_intersect(const rt_mesh& m, const Ray& ray, float& z, uint32_t face, float& bu, float& bv, float det_eps) {
+  const uint32_t* f = &m.pos_idx[3 * (size_t)face];
+  V v0 = from3(&m.positions[3 * (size_t)f[0]]);
+  V v1 = from3(&m.positions[3 * (size_t)f[1]]);
+  V v2 = from3(&m.positions[3 * (size_t)f[2]]);
+  V edge1 = v1 - v0;
+  V edge2 = v2 - v0;
+  V h = cross(ray.dir, edge2);
+  float det = dot(edge1, h);
+  if (fabsf(det) < det_eps) return false;
+  float inv_det = 1.0f / det;
+  V s = ray.p - v0;
+  float u = inv_det * dot(s, h);
+  if (u < 0.0f || u > 1.0f) return false;
+  V q = cross(s, edge1);
+  float v = inv_det * dot(ray.dir, q);
+  if (v < 0.0f || (u + v) > 1.0f) return false;
+  float t = inv_det * dot(edge2, q);
+  if (t <= det_eps || t >= z) return false;
+  z = t;
+  bu = u;
+  bv = v;
+  return true;
+}
+
+// TriObj::IntersectTriangleShadow — objects.cpp:233-265 (falls off the end => false)
+bool tri_shadow(const rt_mesh& m, const Ray& ray, uint32_t face, float max) {
+  const float epsilon = 0.002f;
+  const uint32_t* f = &m.pos_idx[3 * (size_t)face];
+  V v0 = from3(&m.positions[3 * (size_t)f[0]]);
+  V v1 = from3(&m.positions[3 * (size_t)f[1]]);
+  V v2 = from3(&m.positions[3 * (size_t)f[2]]);
+  V edge1 = v1 - v0;
+  V edge2 = v2 - v0;
+  V h = cross(ray.dir, edge2);
+  float det = dot(edge1, h);
+  if (fabsf(det) < epsilon) return false;
+  float inv_det = 1.0f / det;
+  V s = ray.p - v0;
+  float u = inv_det * dot(s, h);
+  if (u < 0.0f || u > 1.0f) return false;
+  V q = cross(s, edge1);
+  float v = inv_det * dot(ray.dir, q);
+  if (v < 0.0f || (u + v) > 1.0f) return false;
+  float t = inv_det * dot(edge2, q);
+  if (t > epsilon && t < max) return true;
+  return false;
+}
+
+// TriObj::TraceBVHNode — objects.cpp:268-339: both children always visited, fresh HitInfo each.
+bool bvh_trace(const rt_mesh& m, const Ray& ray, Hit& hInfo, uint32_t nodeID, Counters* cnt) {
+  const rt_bvh_node& n = m.bvh[nodeID];
+  float bounds[6] = {n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]};
+  if (cnt) cnt->node_visits++;
+  if (!hit_aabb(ray, bounds)) return false;
+  if (n.b & RT_BVH_LEAF_BIT) {
+    bool hit = false;
+    uint32_t count = n.b & ~RT_BVH_LEAF_BIT;
+    const uint32_t* elements = &m.bvh_elements[n.a];
+    int closestFace = INT_MAX;
+    float bu = 0, bv = 0, tu = 0, tv = 0;
+    float tempZ = BIGFLOAT;
+    for (uint32_t i = 0; i < count; i++) {
+      uint32_t tri = elements[i];
+      if (cnt) cnt->tri_tests++;
+      if (tri_intersect(m, ray, tempZ, tri, tu, tv, 0.002f)) {
+        hit = true;
+        if (tempZ >= hInfo.z) continue;
+        hInfo.z = tempZ;
+        closestFace = (int)tri;
+        bu = tu;
+        bv = tv;
+      }
+    }
+    if (!hit) return false;
+    float u = bu, v = bv, w = 1.0f - u - v;
+    V uvw(0, 0, 0);
+    if (m.uvw_idx && m.uvw) {
+      const uint32_t* ft = &m.uvw_idx[3 * (size_t)closestFace];
+      uvw = (from3(&m.uvw[3 * (size_t)ft[0]]) * w) + (from3(&m.uvw[3 * (size_t)ft[1]]) * u) + (from3(&m.uvw[3 * (size_t)ft[2]]) * v);
+    }
+    const uint32_t* fn = &m.nrm_idx[3 * (size_t)closestFace];
+    hInfo.N = normalized(w * from3(&m.normals[3 * (size_t)fn[0]]) + u * from3(&m.normals[3 * (size_t)fn[1]]) +
+                         v * from3(&m.normals[3 * (size_t)fn[2]]));
+    hInfo.p = ray.p + ray.dir * hInfo.z;
+    hInfo.uvw = uvw;
+    hInfo.z = tempZ;
+    hInfo.front = dot(ray.dir, hInfo.N) < 0;
+    hInfo.face = closestFace;
+    return true;
+  } else {
+    Hit h1, h2;
+    bool hit1 = bvh_trace(m, ray, h1, n.a, cnt);
+    bool hit2 = bvh_trace(m, ray, h2, n.b, cnt);
+    if (h1.z < h2.z) {
+      hInfo = h1;
+      return hit1;
+    } else {
+      hInfo = h2;
+      return hit2;
+    }
+  }
+}
+
+// TriObj::TraceBVHNodeShadow — objects.cpp:341-371
+bool bvh_shadow(const rt_mesh& m, const Ray& ray, float t_max, uint32_t nodeID, Counters* cnt) {
+  const rt_bvh_node& n = m.bvh[nodeID];
+  float bounds[6] = {n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]};
+  if (cnt) cnt->node_visits++;
+  if (!hit_aabb(ray, bounds)) return false;
+  if (n.b & RT_BVH_LEAF_BIT) {
+    uint32_t count = n.b & ~RT_BVH_LEAF_BIT;
+    const uint32_t* elements = &m.bvh_elements[n.a];
+    for (uint32_t i = 0; i < count; i++) {
+      if (cnt) cnt->tri_tests++;
+      if (tri_shadow(m, ray, elements[i], t_max)) return true;
+    }
+    return false;
+  } else {
+    if (bvh_shadow(m, ray, t_max, n.a, cnt)) return true;
+    return bvh_shadow(m, ray, t_max, n.b, cnt);
+  }
+}
+
+// PointLight::IntersectRay — objects.cpp:377-413 (int radius, double arithmetic)
+bool light_intersect(const rt_light& L, const Ray& ray, Hit& h, int hitSide) {
+  V q = from3(L.position);
+  int r = (int)L.size;
+  V oc = ray.p - q;
+  float eps = 0.002f;
+  double a = dot(ray.dir, ray.dir);
+  double b = 2.0 * dot(oc, ray.dir);
+  double c = dot(oc, oc) - r * r;
+  double discriminant = b * b - 4 * a * c;
+  if (discriminant < 0) return false;
+  float sqrt_disc = sqrtf((float)discriminant);
+  float twoA = (float)(2 * a);
+  double t1 = (-b - sqrt_disc) / (twoA);
+  double t2 = (-b + sqrt_disc) / (twoA);
+  if (t1 > eps && (hitSide & RT_HIT_FRONT)) {
+    if (h.z > t1) {
+      h.z = (float)t1;
+      h.p = ray.p + (ray.dir * (float)t1);
+      h.front = true;
+      return true;
+    }
+  } else if (t2 >= eps && (hitSide & RT_HIT_BACK)) {
+    if (h.z > t2) {
+      h.z = (float)t2;
+      h.p = ray.p + (ray.dir * (float)t2);
+      h.front = false;
+      return true;
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------- scene graph (RayTracer.cpp:336-435)
+
+Ray to_node(const rt_node& n, const Ray& r) {  // Transformation::ToNodeCoords, scene.h:183
+  return Ray(xform_point(n.itm, r.p), xform_dir(n.itm, r.dir));
+}
+void from_node(const rt_node& n, Hit& h) {  // Transformation::FromNodeCoords, scene.h:184-189
+  h.p = xform_point(n.tm, h.p);
+  h.N = xform_tmul(n.itm, h.N);
+}
+
+bool object_intersect(const orc_scene& S, const rt_node& n, const Ray& ray, Hit& h, int hitSide, Counters* cnt) {
+  switch (n.prim_kind) {
+    case RT_PRIM_SPHERE:
+      if (cnt) cnt->sphere_tests++;
+      return sphere_intersect(ray, h, hitSide);
+    case RT_PRIM_PLANE:
+      if (cnt) cnt->plane_tests++;
+      return plane_intersect(ray, h, hitSide);
+    case RT_PRIM_MESH: {  // TriObj::IntersectRay, objects.cpp:172-183
+      Hit temp;
+      if (bvh_trace(S.d.meshes[n.mesh_id], ray, temp, 0, cnt)) {
+        h = temp;
+        return true;
+      }
+      return false;
+    }
+  }
+  return false;
+}
+bool object_shadow(const orc_scene& S, const rt_node& n, const Ray& ray, float t_max, Counters* cnt) {
+  switch (n.prim_kind) {
+    case RT_PRIM_SPHERE:
+      if (cnt) cnt->sphere_tests++;
+      return sphere_shadow(ray, t_max);
+    case RT_PRIM_PLANE:
+      if (cnt) cnt->plane_tests++;
+      return plane_shadow(ray, t_max);
+    case RT_PRIM_MESH:
+      return bvh_shadow(S.d.meshes[n.mesh_id], ray, t_max, 0, cnt);
+  }
+  return false;
+}
+
+// RayTracer::TraverseTree — RayTracer.cpp:373-435
+bool traverse(const orc_scene& S, const Ray& ray, int node, Hit& hitInfo, int hitSide, Counters* cnt) {
+  bool hit = false;
+  const rt_node& n = S.d.nodes[node];
+  Ray tr = to_node(n, ray);
+  if (n.prim_kind != RT_PRIM_NONE) {
+    if (cnt) cnt->inst_tests++;
+    Hit local;
+    if (object_intersect(S, n, tr, local, hitSide, cnt)) {
+      if (local.z < hitInfo.z) {
+        hitInfo = local;
+        hit = true;
+        from_node(n, hitInfo);
+        hitInfo.node = node;
+      }
+    }
+  }
+  for (int c : S.children[node]) {
+    Hit local;
+    if (traverse(S, tr, c, local, hitSide, cnt)) {
+      if (local.z < hitInfo.z) {
+        hitInfo = local;
+        hit = true;
+        from_node(n, hitInfo);
+      }
+    }
+  }
+  if (node == 0) {
+    for (uint32_t l = 0; l < S.d.n_lights; l++) {
+      const rt_light& L = S.d.lights[l];
+      if (L.kind == RT_LIGHT_POINT && L.size > 0.0f) {  // IsRenderable, lights.h:62
+        Hit local;
+        if (light_intersect(L, ray, local, RT_HIT_FRONT_AND_BACK)) {
+          if (local.z < hitInfo.z) {
+            hitInfo = local;
+            hit = true;
+            hitInfo.light = (int)l;
+          }
+        }
+      }
+    }
+  }
+  return hit;
+}
+
+// RayTracer::TraverseTreeShadow — RayTracer.cpp:346-371
+bool traverse_shadow(const orc_scene& S, const Ray& ray, int node, float t_max, Counters* cnt) {
+  const rt_node& n = S.d.nodes[node];
+  Ray tr = to_node(n, ray);
+  if (n.prim_kind != RT_PRIM_NONE) {
+    if (cnt) cnt->inst_tests++;
+    if (object_shadow(S, n, tr, t_max, cnt)) return true;
+  }
+  for (int c : S.children[node])
+    if (traverse_shadow(S, tr, c, t_max, cnt)) return true;
+  return false;
+}
+
+// ---------------------------------------------------------------- textures (texture.cpp, scene.h restated)
+
+V tile_clamp(V uvw) {  // scene.h:312-322
+  V u;
+  u.x = uvw.x - (int)uvw.x;
+  u.y = uvw.y - (int)uvw.y;
+  u.z = uvw.z - (int)uvw.z;
+  if (u.x < 0) u.x += 1;
+  if (u.y < 0) u.y += 1;
+  if (u.z < 0) u.z += 1;
+  return u;
+}
+
+Color image_eval(const rt_image& im, V uvw) {  // TextureFile::Eval, texture.cpp:106-132
+  int width = im.width, height = im.height;
+  if (width + height == 0) return Color(0, 0, 0);
+  V u = tile_clamp(uvw);
+  float x = width * u.x;
+  float y = height * u.y;
+  int ix = (int)x;
+  int iy = (int)y;
+  float fx = x - ix;
+  float fy = y - iy;
+  if (ix < 0) ix -= (ix / width - 1) * width;
+  if (ix >= width) ix -= (ix / width) * width;
+  int ixp = ix + 1;
+  if (ixp >= width) ixp -= width;
+  if (iy < 0) iy -= (iy / height - 1) * height;
+  if (iy >= height) iy -= (iy / height) * height;
+  int iyp = iy + 1;
+  if (iyp >= height) iyp -= height;
+  auto tex = [&](int xx, int yy) {
+    const uint8_t* p = &im.rgb[3 * ((size_t)yy * width + xx)];
+    return Color(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f);
+  };
+  return tex(ix, iy) * ((1 - fx) * (1 - fy)) + tex(ixp, iy) * (fx * (1 - fy)) + tex(ix, iyp) * ((1 - fx) * fy) +
+         tex(ixp, iyp) * (fx * fy);
+}
+
+Color eval_tex_color(const orc_scene& S, const rt_tex_color& tc, V uvw, Counters* cnt);
+
+Color eval_map(const orc_scene& S, int map, V uvw, Counters* cnt) {  // TextureMap::Eval, scene.h:337
+  const rt_texmap& tm = S.d.texmaps[map];
+  V u = xform_point(tm.itm, uvw);
+  if (cnt) cnt->tex_evals++;
+  if (tm.kind == RT_TEX_IMAGE) return image_eval(S.d.images[tm.image], u);
+  // TextureChecker::Eval, texture.cpp:136-140
+  V t = tile_clamp(u);
+  int k = (t.x <= 0.5f) ^ (t.y <= 0.5f);
+  return eval_tex_color(S, tm.color[k], u, cnt);
+}
+Color eval_tex_color(const orc_scene& S, const rt_tex_color& tc, V uvw, Counters* cnt) {  // TexturedValue::Eval, scene.h:373
+  Color v = from3(tc.value);
+  if (tc.map < 0) return v;
+  return v * eval_map(S, tc.map, uvw, cnt);
+}
+float eval_tex_float(const orc_scene& S, const rt_tex_float& tf, V uvw, Counters* cnt) {  // scene.h:392
+  if (tf.map < 0) return tf.value;
+  return tf.value * eval_map(S, tf.map, uvw, cnt).x;
+}
+Color eval_environment(const orc_scene& S, const rt_tex_color& tc, V dir, Counters* cnt) {  // scene.h:377-384
+  float len = length(dir);
+  float z = asinf(-dir.z / len) / (float)M_PI + 0.5f;
+  float x = dir.x / (fabsf(dir.x) + fabsf(dir.y));
+  float y = dir.y / (fabsf(dir.x) + fabsf(dir.y));
+  return eval_tex_color(S, tc, V(0.5f + 0.5f * z * (x - y), 0.5f + 0.5f * z * (x + y), 0.0f), cnt);
+}
+
+// ---------------------------------------------------------------- sampling context
+
+struct Sampler {
+  int mode;
+  PCG* pcg;         // RT_SAMPLER_PCG_HALTON: the per-camera-sample copy (RayTracer.cpp:176,227: passed by value)
+  uint32_t key[2];  // RT_SAMPLER_PHILOX
+  uint32_t pixel;
+};
+// One random float at (tree node, block, lane).  Philox: ctr = (pixel, node, block, TAG_SHADE); the offsets are
+// per pixel and tree position, NOT per camera sample — as in the reference, where every sample of a pixel
+// restarts the same stream and only the Halton index changes (SURVEY App. A "Sampler streams").
+float draw(const Sampler& s, uint32_t node, uint32_t block, int lane) {
+  if (s.mode == RT_SAMPLER_PCG_HALTON) return s.pcg->f();
+  uint32_t ctr[4] = {s.pixel, node, block, TAG_SHADE}, out[4];
+  philox(ctr, s.key, out);
+  return u32_to_unit(out[lane]);
+}
+
+struct ShadeCtx {  // ShadowInfo (shadowInfo.h:4-29) + SamplerInfo/ShadeInfo state (renderer.h:107-205)
+  const orc_scene* S;
+  const rt_render_params* P;
+  const Sampler* smp;
+  Counters* cnt;
+  Ray ray;  // normalised direction after SetHit
+  Hit h;
+  int bounce = 0;
+  bool secondary = false;
+  int psample = 0;
+  uint32_t nid = 1;  // position in the recursion tree: refraction child 4n+1, reflection 4n+2, indirect 4n+3
+
+  V Pp() const { return h.p; }
+  V Vv() const { return -ray.dir; }
+  V Nn() const { return h.N; }
+  void set_hit(const Ray& r, const Hit& hh) {  // SamplerInfo::SetHit, renderer.h:142-150
+    h = hh;
+    h.z *= length(r.dir);
+    h.N = normalized(h.N);
+    ray = r;
+    ray.dir = normalized(ray.dir);
+  }
+  bool can_bounce() const { return bounce < P->max_bounces; }   // lights.cpp:130-133
+  bool can_mc() const { return bounce < P->mc_bounces; }        // lights.cpp:138-141
+};
+
+Color shade(const ShadeCtx& info);
+
+// Glossy half-vector shared by ReflectRay / RefractRay (materials.cpp:35-49, 79-94)
+V gloss_half_vector(const ShadeCtx& info, float glossiness, float offsetPhi, float offsetTheta, bool renorm) {
+  float phi = (float)(2.0f * M_PI * fmodf(halton(info.psample, 2) + offsetPhi, 1.0f));
+  float cosTheta = powf(fmodf(halton(info.psample, 3) + offsetTheta, 1.0f), 1.0f / (glossiness + 1.0f));
+  float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
+  float x = sinTheta * cosf(phi);
+  float y = sinTheta * sinf(phi);
+  float z = cosTheta;
+  V t, b;
+  orthonormals(info.Nn(), t, b);
+  V H = (x * t) + (y * b) + (z * info.Nn());
+  if (renorm) H = normalized(H);
+  return H;
+}
+
+// ReflectRay — materials.cpp:30-59.  (block, lane0) select the Philox slots for its two draws.
+Ray reflect_ray(const ShadeCtx& info, float glossiness, uint32_t block, int lane0) {
+  V view = info.Vv();
+  float offsetPhi = draw(*info.smp, info.nid, block, lane0);
+  float offsetTheta = draw(*info.smp, info.nid, block, lane0 + 1);
+  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, false);
+  float d = dot(H, view);
+  V dir = (2 * d) * H - view;
+  dir = normalized(dir);
+  return Ray(info.Pp(), dir);
+}
+
+// RefractRay — materials.cpp:70-133
+Ray refract_ray(float ior, const ShadeCtx& info, float glossiness) {
+  V view = info.Vv();
+  float eps = 1e-4f;
+  float offsetPhi = draw(*info.smp, info.nid, 0, 0);
+  float offsetTheta = draw(*info.smp, info.nid, 0, 1);
+  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, true);
+  Ray refract;
+  if (info.h.front) {
+    float eta = 1 / ior;
+    float etaSq = eta * eta;
+    float NdotV = dot(view, H);
+    float cosThetaT = sqrtf(1 - etaSq * (1 - NdotV * NdotV));
+    V dir = -eta * view - (cosThetaT - eta * NdotV) * H;
+    refract = Ray(info.Pp(), normalized(dir));
+    float sign = dot(refract.dir, info.Nn()) > 0.0f ? 1.0f : -1.0f;
+    refract.p = refract.p + info.Nn() * (eps * sign);
+  } else {
+    float eta = ior;
+    V Hb = -H;
+    V negN = -info.Nn();
+    float NdotV = dot(view, Hb);
+    float etaSq = eta * eta;
+    float cosThetaSquared = (float)(1.0 - etaSq * (1 - NdotV * NdotV));
+    if (cosThetaSquared < 0.0f) return reflect_ray(info, glossiness, 1, 0);  // total internal reflection
+    float cosThetaT = sqrtf(cosThetaSquared);
+    V dir = -eta * view - (cosThetaT - eta * NdotV) * Hb;
+    refract = Ray(info.Pp(), normalized(dir));
+    float sign = dot(refract.dir, negN) > 0.0f ? 1.0f : -1.0f;
+    refract.p = refract.p + negN * (eps * sign);
+  }
+  return refract;
+}
+
+// ShadowInfo::TraceSecondaryRay — lights.cpp:167-212.  child_slot: 1 refraction, 2 reflection, 3 indirect.
+Color trace_secondary(const ShadeCtx& info, const Ray& ray, float& dist, bool reflection, int child_slot) {
+  const orc_scene& S = *info.S;
+  Hit hit;
+  if (reflection) {
+    if (dot(ray.dir, info.Nn()) < 0) {  // reflected below the surface: re-shade the same point
+      ShadeCtx si = info;
+      hit = info.h;
+      si.set_hit(ray, hit);
+      si.bounce++;
+      si.secondary = true;
+      si.nid = info.nid * 4 + child_slot;
+      dist = 0;  // uninitialised in the reference; 0 => no absorption
+      return shade(si);
+    }
+  }
+  if (info.cnt) info.cnt->rays_secondary++;
+  if (traverse(S, ray, 0, hit, RT_HIT_FRONT_AND_BACK, info.cnt)) {
+    if (hit.light < 0) {
+      ShadeCtx si = info;
+      si.set_hit(ray, hit);
+      si.bounce++;
+      dist = si.h.front ? si.h.z : 0;
+      si.secondary = true;
+      si.nid = info.nid * 4 + child_slot;
+      return shade(si);
+    } else {
+      dist = hit.z;
+      return Color(1, 1, 1);
+    }
+  } else {
+    dist = BIGFLOAT;
+    return eval_environment(S, S.d.environment, ray.dir, info.cnt);
+  }
+}
+
+// SampleIndirectDiffuseCosin — materials.cpp:175-212 (dead code in the reference; spec for config 3)
+Color sample_indirect_cosine(const ShadeCtx& info) {
+  float offset = draw(*info.smp, info.nid, 1, 2);
+  float offset2 = draw(*info.smp, info.nid, 1, 3);
+  Color total(0, 0, 0);
+  int mcs = info.P->mc_samples;
+  for (int i = 0; i < mcs; i++) {
+    int hi = (info.psample * mcs + i) % 1000;
+    float u1 = fmodf(info.S->hphi[hi] + offset, 1.0f);
+    float u2 = fmodf(info.S->htheta[hi] + offset2, 1.0f);
+    float r = sqrtf(u1);
+    float phi = (float)(2.0f * M_PI * u2);
+    float x = r * cosf(phi);
+    float y = r * sinf(phi);
+    float z = sqrtf(1.0f - u1);
+    V N = info.Nn();
+    V t, b;
+    orthonormals(N, t, b);
+    V direction = (x * t) + (y * b) + (z * N);
+    direction = normalized(direction);
+    Ray indirect(info.Pp(), direction);
+    float dist;
+    total = total + trace_secondary(info, indirect, dist, false, 3);
+  }
+  return total / (float)mcs;
+}
+
+float trace_shadow(const ShadeCtx& info, const Ray& ray, float t_max) {  // lights.cpp:122-125
+  if (info.cnt) info.cnt->rays_shadow++;
+  return traverse_shadow(*info.S, ray, 0, t_max, info.cnt) ? 0.0f : 1.0f;
+}
+
+// PointLight::Illuminate — lights.cpp:19-72
+Color point_illuminate(const ShadeCtx& info, const rt_light& L, uint32_t light_index, V& dir) {
+  const orc_scene& S = *info.S;
+  V position = from3(L.position);
+  float size = L.size * info.P->light_size_scale;
+  V toShadingPoint = info.Pp() - position;
+  toShadingPoint = normalized(toShadingPoint);
+  float randXOffset = draw(*info.smp, info.nid, 2 + light_index, 0);
+  float randYOffset = draw(*info.smp, info.nid, 2 + light_index, 1);
+  int numSamples = 0;
+  const float twoPi = (float)(2 * M_PI);
+  float summedLight = 0.0f;
+  V tangent, bitangent;
+  orthonormals(toShadingPoint, tangent, bitangent);
+  if (size == 0.0f && info.P->dedup_hard_shadows) {
+    // all 16/128 rays are identical for a size-0 light; fire one.
+    V toLight = position - info.Pp();
+    float dist = length(toLight);
+    summedLight = trace_shadow(info, Ray(info.Pp(), toLight / dist), dist);
+    numSamples = 1;
+  } else {
+    for (int i = 0; i < info.P->shadow_max; i++) {
+      float discX = S.h2[i % 128] + randXOffset;
+      float discY = S.h3[i % 128] + randYOffset;
+      discX -= (discX > 1.0f) ? 1.0f : 0.0f;
+      discY -= (discY > 1.0f) ? 1.0f : 0.0f;
+      float r = sqrtf(discX) * size;
+      float angle = twoPi * discY;
+      float offsetU = r * cosf(angle);
+      float offsetV = r * sinf(angle);
+      V lightSamplePoint = position + (tangent * offsetU) + (bitangent * offsetV);
+      V toLight = lightSamplePoint - info.Pp();
+      float dist = length(toLight);
+      V shadowRayDir = toLight / dist;
+      summedLight += trace_shadow(info, Ray(info.Pp(), shadowRayDir), dist);
+      numSamples++;
+      if (numSamples == info.P->shadow_min && summedLight == numSamples) break;
+    }
+  }
+  dir = position - info.Pp();
+  float dist = length(dir);
+  dir = normalized(dir);
+  summedLight /= (float)numSamples;
+  Color full = from3(L.intensity) * summedLight;
+  if (L.attenuation) return full / (dist * dist);  // boolean attenuation, SURVEY Q9
+  return full;
+}
+
+// MtlBlinn::Shade — materials.cpp:222-331
+Color shade(const ShadeCtx& info) {
+  const orc_scene& S = *info.S;
+  if (info.cnt) info.cnt->shades++;
+  const rt_material& M = node_material(S, info.h.node);
+  if (M.kind != RT_MTL_BLINN) return Color(1.0f, 1.0f, 1.0f);  // materials.cpp:396-408
+  Color finalColor(0, 0, 0), ambientLight(0, 0, 0), reflectCol(0, 0, 0), refractCol(0, 0, 0), indirect(0, 0, 0);
+  V uvw = info.h.uvw;
+  Color reflection = eval_tex_color(S, M.reflection, uvw, info.cnt);
+  Color refraction = eval_tex_color(S, M.refraction, uvw, info.cnt);
+  Color kd = eval_tex_color(S, M.diffuse, uvw, info.cnt);
+  Color ks = eval_tex_color(S, M.specular, uvw, info.cnt);
+  float alpha = eval_tex_float(S, M.glossiness, uvw, info.cnt);
+  Color emission = eval_tex_color(S, M.emission, uvw, info.cnt);
+
+  float diffScalar = (float)(1 / M_PI);
+  float specScalar = (float)((alpha + 2) / (8 * M_PI));
+  Color cKd = kd * diffScalar;
+  Color cKs = ks * specScalar;
+  Color fullReflection = reflection;
+  float matior = M.ior;
+  Color absorption = from3(M.absorption);
+  auto nonzero = [](Color c) { return c.x != 0 || c.y != 0 || c.z != 0; };
+  auto absorbs = [&]() { return absorption.x > 0.0f || absorption.y > 0.0f || absorption.z > 0.0f; };
+
+  bool needsRefraction = (matior > 0.0f && info.can_bounce() && nonzero(refraction));
+  if (needsRefraction) {
+    float iorRatio = (1.0f - matior) / (1.0f + matior);
+    Color fresnel = refraction * (iorRatio * iorRatio);
+    Color fullR = fullReflection + fresnel;
+    Color weight = refraction * (Color(1, 1, 1) - fullR);
+    // In PCG mode the draws are sequential, so the ray must be built even if it will be weighted by 0.
+    bool skip = info.P->skip_zero_weight && !nonzero(weight) && info.smp->mode == RT_SAMPLER_PHILOX;
+    if (!skip) {
+      float dist;
+      Ray refract = refract_ray(M.ior, info, M.glossiness.value);
+      // a refract_ray that fell back to total internal reflection is still traced as a refraction ray
+      refractCol = trace_secondary(info, refract, dist, false, 1);
+      if (dist > 0.0f && absorbs()) {
+        refractCol.x *= expf(-absorption.x * dist);
+        refractCol.y *= expf(-absorption.y * dist);
+        refractCol.z *= expf(-absorption.z * dist);
+      }
+      refractCol = refraction * refractCol;
+    }
+    fullReflection = fullR;
+    refractCol = refractCol * (Color(1, 1, 1) - fullReflection);
+  }
+
+  if (nonzero(fullReflection) && info.can_bounce()) {
+    bool skip = info.P->skip_zero_weight && !nonzero(reflection) && info.smp->mode == RT_SAMPLER_PHILOX;
+    if (!skip) {
+      float dist;
+      Ray reflect = reflect_ray(info, M.glossiness.value, 0, 2);
+      reflectCol = trace_secondary(info, reflect, dist, true, 2);
+      if (dist > 0.0f && absorbs()) {
+        reflectCol.x *= expf(-absorption.x * dist);
+        reflectCol.y *= expf(-absorption.y * dist);
+        reflectCol.z *= expf(-absorption.z * dist);
+      }
+      reflectCol = reflection * reflectCol;
+    }
+  }
+
+  for (uint32_t i = 0; i < S.d.n_lights; i++) {
+    const rt_light& L = S.d.lights[i];
+    V lightDir;
+    Color lightIntensity;
+    if (L.kind == RT_LIGHT_AMBIENT) {
+      ambientLight = ambientLight + from3(L.intensity);  // accumulated, never added
+      continue;
+    } else if (L.kind == RT_LIGHT_DIRECT) {  // lights.h:45
+      lightDir = -from3(L.direction);
+      lightIntensity = from3(L.intensity) * trace_shadow(info, Ray(info.Pp(), lightDir), BIGFLOAT);
+    } else {
+      lightIntensity = point_illuminate(info, L, i, lightDir);
+    }
+    V h = normalized(lightDir + info.Vv());
+    float cosphi = std::max(dot(info.Nn(), h), 0.0f);
+    float costheta = std::max(dot(lightDir, info.Nn()), 0.0f);
+    finalColor = finalColor + (lightIntensity * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
+  }
+
+  if (info.P->mc_bounces > 0 && info.can_mc()) {  // materials.cpp:310-312 (commented out in the reference)
+    indirect = indirect + sample_indirect_cosine(info) * kd;
+  } else if (info.P->photons) {  // materials.cpp:315-322
+    if (info.secondary) {
+      Color irr = S.cmap.estimate(info.Pp(), info.Nn(), info.P->photon_radius, info.P->ellipticity_caustic, info.P->photon_k, info.cnt);
+      indirect = indirect + (float)(1.0f / M_PI) * kd * irr;
+    } else {
+      Color irr = S.pmap.estimate(info.Pp(), info.Nn(), info.P->photon_radius, info.P->ellipticity_global, info.P->photon_k, info.cnt);
+      indirect = indirect + (float)(1.0f / M_PI) * kd * irr;
+    }
+  }
+  finalColor = finalColor + indirect;
+  finalColor = finalColor + reflectCol;
+  finalColor = finalColor + refractCol;
+  finalColor = finalColor + emission;
+  return finalColor;
+}
+
+// ---------------------------------------------------------------- camera (RayTracer.cpp:15-22, 93-174)
+
+struct CamConsts {
+  V X, Y, Z, pos;
+  float l, wh, ww, camW, camH, dof;
+  int W, H;
+};
+CamConsts cam_consts(const orc_scene& S, const rt_render_params& P) {
+  const rt_camera& c = S.d.camera;
+  CamConsts k;
+  k.W = P.width > 0 ? P.width : c.width;
+  k.H = P.height > 0 ? P.height : c.height;
+  V dir = from3(c.dir), up = from3(c.up);
+  k.Z = -dir;                // RayTracer.cpp:17
+  k.Y = up;                  // :18
+  k.X = cross(k.Y, k.Z);     // :19
+  k.pos = from3(c.pos);
+  k.l = c.focaldist;
+  k.camW = (float)k.W;
+  k.camH = (float)k.H;
+  k.wh = (float)(2.0f * k.l * tan(((double)c.fov * M_PI / 180.0) / 2.0f));  // :100
+  k.ww = k.wh * (k.camW / k.camH);                                           // :101
+  k.dof = c.dof;
+  return k;
+}
+
+void pixel_offsets(const rt_render_params& P, int index, PCG* pcg_out, float& ro, float& roy) {
+  if (P.sampler == RT_SAMPLER_PCG_HALTON) {  // RayTracer.cpp:129-131
+    PCG rng((uint64_t)index);
+    ro = rng.f();
+    roy = rng.f();
+    if (pcg_out) *pcg_out = rng;
+  } else {
+    uint32_t ctr[4] = {(uint32_t)index, 0, 0, TAG_PIXEL}, key[2] = {P.seed_lo, P.seed_hi}, out[4];
+    philox(ctr, key, out);
+    ro = u32_to_unit(out[0]);
+    roy = u32_to_unit(out[1]);
+  }
+}
+
+Ray primary_ray(const orc_scene& S, const rt_render_params& P, const CamConsts& k, int x, int y, int i, float ro, float roy) {
+  float hx = 0, hy = 0;
+  V camOff(0, 0, 0);
+  if (P.pixel_jitter) {
+    hx = S.h2[i % 128] + ro;            // RayTracer.cpp:138-144 (Y also uses randomOffset)
+    if (hx > 1.0f) hx -= 1.0f;
+    hy = S.h3[i % 128] + ro;
+    if (hy > 1.0f) hy -= 1.0f;
+    float discX = S.h5[i % 128] + ro;   // :152-157
+    float discY = S.h7[i % 128] + roy;
+    if (discX > 1.0f) discX -= 1.0f;
+    if (discY > 1.0f) discY -= 1.0f;
+    float r = sqrtf(discX);
+    float angle = (float)(2.0f * M_PI * discY);
+    float lensU = r * k.dof * cosf(angle);
+    float lensV = r * k.dof * sinf(angle);
+    camOff = V(lensU, lensV, 0.0f);
+  }
+  float pixX = -(k.ww / 2.0f) + ((k.ww * (x + (1.0f / 2.0f) + hx) / k.camW));   // :147
+  float pixY = (k.wh / 2.0f) - ((k.wh * (y + (1.0f / 2.0f) + hy) / k.camH));    // :148
+  V pixelPos(pixX, pixY, -k.l);
+  auto rot = [&](V v) { return k.X * v.x + k.Y * v.y + k.Z * v.z; };            // cam2Wrld * (v, 0), :165-166
+  V worldCamera = rot(camOff);
+  V worldPixel = rot(pixelPos);
+  V origin = k.pos + worldCamera;
+  V dir = worldPixel - worldCamera;
+  return Ray(origin, dir);
+}
+
+// RayTracer::SendRay — RayTracer.cpp:227-259
+Color send_ray(const orc_scene& S, const rt_render_params& P, int i, const Ray& ray, int x, int y, int W, int H,
+               const Sampler& smp, Counters* cnt, Hit* primary_out) {
+  Hit hit;
+  if (cnt) { cnt->rays_primary++; cnt->paths++; }
+  bool ok = traverse(S, ray, 0, hit, RT_HIT_FRONT, cnt);
+  if (primary_out) *primary_out = hit;
+  if (ok) {
+    if (hit.light < 0) {
+      ShadeCtx info;
+      info.S = &S; info.P = &P; info.smp = &smp; info.cnt = cnt;
+      info.psample = i;
+      info.set_hit(ray, hit);
+      return shade(info);
+    } else {
+      const rt_light& L = S.d.lights[hit.light];  // Radiance of the light that was hit (lights.h:60)
+      return from3(L.intensity) / ((float)M_PI * L.size * L.size);
+    }
+  } else {
+    float u = (float)x / (float)W;
+    float v = (float)y / (float)H;
+    return eval_tex_color(S, S.d.background, V(u, v, 0.0f), cnt);
+  }
+}
+
+const float T_VALUES[71] = {0,     12.706f, 4.303f, 3.182f, 2.776f, 2.571f, 2.447f, 2.365f, 2.306f, 2.262f, 2.228f, 2.201f,
+                            2.179f, 2.160f, 2.145f, 2.131f, 2.120f, 2.110f, 2.101f, 2.093f, 2.086f, 2.080f, 2.074f, 2.069f,
+                            2.064f, 2.060f, 2.056f, 2.052f, 2.048f, 2.045f, 2.042f, 2.040f, 2.037f, 2.035f, 2.032f, 2.030f,
+                            2.028f, 2.026f, 2.024f, 2.023f, 2.021f, 2.020f, 2.018f, 2.017f, 2.015f, 2.014f, 2.013f, 2.012f,
+                            2.011f, 2.010f, 2.009f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f,
+                            2.000f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f};  // raytracer.h:52-58
+
+struct RenderJob {
+  orc_scene* S;
+  rt_render_params P;
+  rt_framebuffer* fb;
+  CamConsts k;
+  std::atomic<int> next_tile{0};
+  int tiles_x, tiles_y;
+  std::vector<int> tile_list;
+};
+
+// Per-pixel loop of RunThread — RayTracer.cpp:117-216
+void render_pixel(RenderJob& job, int x, int y, Counters* cnt) {
+  orc_scene& S = *job.S;
+  const rt_render_params& P = job.P;
+  const int W = job.k.W, H = job.k.H;
+  int index = y * W + x;
+  Color sum(0, 0, 0), sumSq(0, 0, 0);
+  PCG rng0;
+  float ro, roy;
+  pixel_offsets(P, index, &rng0, ro, roy);
+  Sampler smp;
+  smp.mode = P.sampler;
+  smp.key[0] = P.seed_lo; smp.key[1] = P.seed_hi;
+  smp.pixel = (uint32_t)index;
+  int begin = P.sample_begin;
+  int count = P.sample_count > 0 ? P.sample_count : P.spp_max - begin;
+  int end = begin + count;
+  bool adaptive = P.spp_min < P.spp_max && begin == 0 && end == P.spp_max;
+  int total = 0;
+  Hit first;
+  for (int i = begin; i < end; i++) {
+    Ray ray = primary_ray(S, P, job.k, x, y, i, ro, roy);
+    PCG rng = rng0;  // passed by value: every sample restarts the same stream (RayTracer.cpp:176,227)
+    smp.pcg = &rng;
+    Color c = send_ray(S, P, i, ray, x, y, W, H, smp, cnt, i == begin ? &first : nullptr);
+    sum = sum + c;
+    sumSq = sumSq + c * c;
+    if (adaptive && i >= P.spp_min) {  // RayTracer.cpp:180-198
+      float n = (float)(i + 1);
+      Color meanSq = sum * sum;
+      Color variance = (sumSq - meanSq / n) / (n - 1.0f);
+      variance.x = std::max(variance.x, 0.0f); variance.y = std::max(variance.y, 0.0f); variance.z = std::max(variance.z, 0.0f);
+      Color stdDev(sqrtf(variance.x), sqrtf(variance.y), sqrtf(variance.z));
+      int ti = (int)n - 1;
+      if (ti > 70) ti = 70;  // the table has 71 entries
+      float t = T_VALUES[ti];
+      Color phi = t * (stdDev / sqrtf(n));
+      if (phi.x <= P.adaptive_threshold && phi.y <= P.adaptive_threshold && phi.z <= P.adaptive_threshold) {
+        total = i + 1;
+        break;
+      }
+    }
+  }
+  if (total == 0) total = end - begin;  // fall-through leaves 0 in the reference
+  Color final = sum / (float)total;
+  rt_framebuffer* fb = job.fb;
+  if (fb->radiance) {
+    fb->radiance[4 * (size_t)index + 0] = final.x; fb->radiance[4 * (size_t)index + 1] = final.y;
+    fb->radiance[4 * (size_t)index + 2] = final.z; fb->radiance[4 * (size_t)index + 3] = (float)total;
+  }
+  if (S.d.camera.srgb) final = Color(linear_to_srgb(final.x), linear_to_srgb(final.y), linear_to_srgb(final.z));  // :208-211
+  if (fb->rgb8) {
+    fb->rgb8[3 * (size_t)index + 0] = to_byte(final.x); fb->rgb8[3 * (size_t)index + 1] = to_byte(final.y);
+    fb->rgb8[3 * (size_t)index + 2] = to_byte(final.z);
+  }
+  if (fb->sample_count) fb->sample_count[index] = total;
+  if (fb->hit_node) fb->hit_node[index] = first.light >= 0 ? -2 - first.light : first.node;
+  if (fb->hit_face) fb->hit_face[index] = first.light >= 0 ? -1 : first.face;
+}
+
+void run_thread(RenderJob* job, Counters* cnt) {  // RayTracer.cpp:93-116: 32x32 tiles off one atomic
+  const int tileSize = 32;
+  for (;;) {
+    int ti = job->next_tile.fetch_add(1, std::memory_order_relaxed);
+    if (ti >= (int)job->tile_list.size()) break;
+    int tileIndex = job->tile_list[ti];
+    int tileX = tileIndex % job->tiles_x, tileY = tileIndex / job->tiles_x;
+    int x0 = tileX * tileSize, y0 = tileY * tileSize;
+    int x1 = std::min(x0 + tileSize, job->k.W), y1 = std::min(y0 + tileSize, job->k.H);
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) render_pixel(*job, x, y, cnt);
+  }
+}
+
+// ---------------------------------------------------------------- photons (RayTracer.cpp:262-334)
+
+struct PhotonRng {
+  uint32_t key[2];
+  uint32_t photon;
+  float get(uint32_t bounce, uint32_t block, int lane) const {
+    uint32_t ctr[4] = {photon, bounce, block, TAG_PHOTON}, out[4];
+    philox(ctr, key, out);
+    return u32_to_unit(out[lane]);
+  }
+};
+
+// PointLight::RandomPhoton — lights.cpp:74-109
+void random_photon(const rt_light& L, const PhotonRng& rng, Ray& r, Color& c) {
+  float u1 = rng.get(0xFFFFFFFFu, 0, 0);
+  float u2 = rng.get(0xFFFFFFFFu, 0, 1);
+  float phi = (float)(2.0f * M_PI * u2);
+  float cosTheta = 1.0f - 2.0f * u1;
+  float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+  V spherePoint(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+  V origin = from3(L.position) + (spherePoint * L.size);
+  V normal = spherePoint;
+  float u3 = rng.get(0xFFFFFFFFu, 0, 2);
+  float u4 = rng.get(0xFFFFFFFFu, 0, 3);
+  float r_hemi = sqrtf(u3);
+  float phi_hemi = (float)(2.0f * M_PI * u4);
+  V t, b;
+  orthonormals(normal, t, b);
+  V dir = (r_hemi * cosf(phi_hemi) * t) + (r_hemi * sinf(phi_hemi) * b) + (sqrtf(1.0f - u3) * normal);
+  dir = normalized(dir);
+  r = Ray(origin, dir);
+  c = from3(L.intensity) * (float)(4 * M_PI) * L.size * L.size;
+}
+
+enum { LOBE_NONE = 0, LOBE_DIFFUSE = 1, LOBE_SPECULAR = 2, LOBE_TRANSMISSION = 4 };  // scene.h:224-231
+
+// RayTracer::TracePhoton (RayTracer.cpp:296-334) + MtlBlinn::GenerateSample (materials.cpp:335-390), iterative.
+void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, const PhotonRng& rng, Counters* cnt) {
+  int prevLobe = LOBE_NONE;
+  int max_b = P.photon_max_bounces > 0 ? P.photon_max_bounces : 64;
+  for (int bounce = 0; bounce < max_b; bounce++) {
+    Hit h;
+    if (cnt) cnt->rays_photon++;
+    if (!traverse(S, ray, 0, h, RT_HIT_FRONT, cnt)) return;
+    if (h.node < 0) return;  // a renderable light was hit: hInfo.node is null (RayTracer.cpp:299)
+    const rt_material& M = node_material(S, h.node);
+    if (M.kind != RT_MTL_BLINN) return;  // MtlPhong/MtlMicrofacet::GenerateSample return false
+    // SamplerInfo over the photon's own stream; pSample = 0 (renderer.h:160)
+    Sampler smp;
+    smp.mode = RT_SAMPLER_PHILOX;
+    smp.pcg = nullptr;
+    ShadeCtx si;
+    si.S = &S; si.P = &P; si.smp = &smp; si.cnt = cnt;
+    si.psample = 0;
+    si.set_hit(ray, h);
+    // draws for this bounce come from the photon stream, not from draw(): re-route via lambdas
+    float random = rng.get((uint32_t)bounce, 0, 0);
+    Color kdv = from3(M.diffuse.value), ksv = from3(M.specular.value), rfv = from3(M.refraction.value);
+    auto gray = [](Color q) { return (q.x + q.y + q.z) / 3.0f; };
+    float diffuseProb = gray(kdv), reflectProb = gray(ksv), refractProb = gray(rfv);
+    V newDir;
+    Color mult;
+    float prob;
+    int lobe;
+    // gloss offsets for Reflect/Refract in the photon stream
+    struct PhotonDraws {
+      float phi, theta, tphi, ttheta;
+    } pd = {rng.get((uint32_t)bounce, 1, 0), rng.get((uint32_t)bounce, 1, 1), rng.get((uint32_t)bounce, 1, 2),
+            rng.get((uint32_t)bounce, 1, 3)};
+    auto photon_reflect = [&](float oPhi, float oTheta) {
+      V view = si.Vv();
+      V H = gloss_half_vector(si, M.glossiness.value, oPhi, oTheta, false);
+      float d = dot(H, view);
+      return normalized((2 * d) * H - view);
+    };
+    if (random < diffuseProb) {
+      float u1 = rng.get((uint32_t)bounce, 0, 1);
+      float u2 = rng.get((uint32_t)bounce, 0, 2);
+      float phi = (float)(2.0f * M_PI * u2);
+      float cosTheta = u1;
+      float sinTheta = sqrtf(1.0f - u1 * u1);
+      float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosTheta;
+      V N = si.Nn(), t, b;
+      orthonormals(N, t, b);
+      newDir = normalized((x * t) + (y * b) + (z * N));
+      mult = kdv;
+      prob = diffuseProb;
+      lobe = LOBE_DIFFUSE;
+    } else if (random < diffuseProb + reflectProb) {
+      newDir = photon_reflect(pd.phi, pd.theta);
+      mult = ksv * dot(newDir, si.Nn());
+      lobe = LOBE_SPECULAR;
+      prob = reflectProb;
+    } else if (random < diffuseProb + reflectProb + refractProb) {
+      // RefractRay with the photon stream's offsets (materials.cpp:70-133); only the direction is used (:380)
+      V view = si.Vv();
+      V H = gloss_half_vector(si, M.glossiness.value, pd.phi, pd.theta, true);
+      if (si.h.front) {
+        float eta = 1 / M.ior;
+        float etaSq = eta * eta;
+        float NdotV = dot(view, H);
+        float cosThetaT = sqrtf(1 - etaSq * (1 - NdotV * NdotV));
+        newDir = normalized(-eta * view - (cosThetaT - eta * NdotV) * H);
+      } else {
+        float eta = M.ior;
+        V Hb = -H;
+        float NdotV = dot(view, Hb);
+        float etaSq = eta * eta;
+        float cosThetaSquared = (float)(1.0 - etaSq * (1 - NdotV * NdotV));
+        if (cosThetaSquared < 0.0f) newDir = photon_reflect(pd.tphi, pd.ttheta);
+        else {
+          float cosThetaT = sqrtf(cosThetaSquared);
+          newDir = normalized(-eta * view - (cosThetaT - eta * NdotV) * Hb);
+        }
+      }
+      mult = rfv * fabsf(dot(newDir, si.Nn()));
+      lobe = LOBE_TRANSMISSION;
+      prob = refractProb;
+    } else {
+      return;  // absorbed
+    }
+    Color newC = c * mult / prob;
+    Ray photonRay(h.p, newDir);
+    if (lobe & LOBE_DIFFUSE) {
+      if ((prevLobe & LOBE_TRANSMISSION) || (prevLobe & LOBE_SPECULAR)) {
+        if (S.cmap.remaining() > 0) S.cmap.add(si.Pp(), -photonRay.dir, newC);
+      } else {
+        if (S.pmap.remaining() > 0) S.pmap.add(si.Pp(), -photonRay.dir, newC);
+      }
+    }
+    prevLobe = lobe;
+    ray = photonRay;
+    c = newC;
+  }
+}
+
+int build_photons(orc_scene& S, const rt_render_params& P, Counters* cnt) {  // GeneratePhotons, RayTracer.cpp:262-294
+  S.pmap.resize(P.n_photons);
+  S.cmap.resize(P.n_photons);
+  std::vector<int> plights;
+  for (uint32_t l = 0; l < S.d.n_lights; l++)
+    if (S.d.lights[l].kind == RT_LIGHT_POINT) plights.push_back((int)l);  // IsPhotonSource, lights.h:63
+  size_t idx = 0;
+  const size_t n = plights.size();
+  long limit = P.photon_emit_limit > 0 ? P.photon_emit_limit : 20L * P.n_photons;
+  uint32_t emitted = 0;
+  while ((S.pmap.remaining() > 0 || S.cmap.remaining() > 0) && n > 0 && (long)emitted < limit) {
+    const rt_light& L = S.d.lights[plights[idx]];
+    PhotonRng rng;
+    rng.key[0] = P.seed_lo; rng.key[1] = P.seed_hi;
+    rng.photon = emitted;
+    Ray ray;
+    Color c;
+    random_photon(L, rng, ray, c);
+    trace_photon(S, P, ray, c, rng, cnt);
+    idx = (idx + 1) % n;
+    emitted++;
+  }
+  S.pmap.scale(1.0f / (float)P.n_photons);  // RayTracer.cpp:290 (1/capacity)
+  S.cmap.scale(1.0f / (float)P.n_photons);
+  S.pmap_raw.assign(S.pmap.photons.begin() + 1, S.pmap.photons.begin() + 1 + S.pmap.stored);
+  S.cmap_raw.assign(S.cmap.photons.begin() + 1, S.cmap.photons.begin() + 1 + S.cmap.stored);
+  S.pmap.prepare();
+  S.cmap.prepare();
+  S.photons_built = true;
+  return (int)emitted;
+}
+
+void hit_to_c(const Hit& h, bool ok, rt_hit* o) {
+  o->p[0] = h.p.x; o->p[1] = h.p.y; o->p[2] = h.p.z;
+  o->z = ok ? h.z : BIGFLOAT;
+  o->N[0] = h.N.x; o->N[1] = h.N.y; o->N[2] = h.N.z;
+  o->uvw[0] = h.uvw.x; o->uvw[1] = h.uvw.y; o->uvw[2] = h.uvw.z;
+  o->node = ok && h.light < 0 ? h.node : -1;
+  o->face = ok && h.light < 0 ? h.face : -1;
+  o->light = ok ? h.light : -1;
+  o->front = h.front ? 1 : 0;
+}
+
+}  // namespace
+
+// ================================================================= C-ABI
+extern "C" {
+
+orc_scene* orc_scene_create(const rt_scene_desc* desc) {
+  if (!desc || !desc->nodes || desc->n_nodes == 0) return nullptr;
+  orc_scene* s = new orc_scene;
+  s->d = *desc;
+  s->children.resize(desc->n_nodes);
+  for (uint32_t i = 1; i < desc->n_nodes; i++) {
+    int p = desc->nodes[i].parent;
+    if (p < 0 || p >= (int)i) { delete s; return nullptr; }
+    s->children[p].push_back((int)i);
+  }
+  s->h2.resize(128); s->h3.resize(128); s->h5.resize(128); s->h7.resize(128);
+  for (int i = 0; i < 128; i++) {  // HaltonSeq<128>::Precompute, rng.h:123
+    s->h2[i] = halton(i, 2); s->h3[i] = halton(i, 3); s->h5[i] = halton(i, 5); s->h7[i] = halton(i, 7);
+  }
+  s->hphi.resize(1000); s->htheta.resize(1000);
+  for (int i = 0; i < 1000; i++) { s->hphi[i] = halton(i, 2); s->htheta[i] = halton(i, 3); }
+  rt_material& m = s->default_mtl;  // MtlBasePhongBlinn defaults, materials.h:53-60
+  std::memset(&m, 0, sizeof m);
+  m.kind = RT_MTL_BLINN;
+  m.diffuse = {{0.5f, 0.5f, 0.5f}, -1};
+  m.specular = {{0.7f, 0.7f, 0.7f}, -1};
+  m.glossiness = {20.0f, -1};
+  m.emission = {{0, 0, 0}, -1};
+  m.reflection = {{0, 0, 0}, -1};
+  m.refraction = {{0, 0, 0}, -1};
+  m.ior = 1.5f;
+  return s;
+}
+void orc_scene_destroy(orc_scene* s) { delete s; }
+
+void orc_trace_closest(const orc_scene* s, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits) {
+  for (size_t i = 0; i < n; i++) {
+    Ray r(from3(rays[i].p), from3(rays[i].dir));
+    Hit h;
+    bool ok = traverse(*s, r, 0, h, hit_side, nullptr);
+    hit_to_c(h, ok, &hits[i]);
+  }
+}
+void orc_trace_any(const orc_scene* s, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded) {
+  for (size_t i = 0; i < n; i++) {
+    Ray r(from3(rays[i].p), from3(rays[i].dir));
+    occluded[i] = traverse_shadow(*s, r, 0, t_max ? t_max[i] : BIGFLOAT, nullptr) ? 1 : 0;
+  }
+}
+
+int orc_photons_build(orc_scene* s, const rt_render_params* params, rt_counters* counters) {
+  Counters c;
+  int e = build_photons(*s, *params, &c);
+  if (counters) c.store(counters);
+  return e;
+}
+int orc_photons_count(const orc_scene* s, int which) { return which ? s->cmap.stored : s->pmap.stored; }
+int orc_photons_download(const orc_scene* s, int which, rt_photon* out, int32_t capacity) {
+  const std::vector<rt_photon>& v = which ? s->cmap_raw : s->pmap_raw;
+  int n = std::min<int>((int)v.size(), capacity);
+  if (n > 0) std::memcpy(out, v.data(), (size_t)n * sizeof(rt_photon));
+  return n;
+}
+int orc_photons_set(orc_scene* s, int which, const rt_photon* photons, int32_t n) {
+  PhotonMapO& m = which ? s->cmap : s->pmap;
+  m.resize(n);
+  for (int i = 0; i < n; i++) m.photons[(size_t)i + 1] = photons[i];
+  m.stored = n;
+  (which ? s->cmap_raw : s->pmap_raw).assign(photons, photons + n);
+  m.prepare();
+  s->photons_built = true;
+  return 0;
+}
+void orc_photon_gather(const orc_scene* s, int which, const float* P, const float* N, size_t n, float radius,
+                       float ellipticity, int k, float* irradiance) {
+  const PhotonMapO& m = which ? s->cmap : s->pmap;
+  for (size_t i = 0; i < n; i++) {
+    Color c = m.estimate(from3(&P[3 * i]), from3(&N[3 * i]), radius, ellipticity, k, nullptr);
+    irradiance[3 * i] = c.x; irradiance[3 * i + 1] = c.y; irradiance[3 * i + 2] = c.z;
+  }
+}
+
+int orc_render(orc_scene* s, const rt_render_params* params, rt_framebuffer* fb, int n_threads, rt_counters* counters) {
+  if (!s || !params || !fb) return RT_ERR_INVALID;
+  RenderJob job;
+  job.S = s;
+  job.P = *params;
+  job.fb = fb;
+  job.k = cam_consts(*s, *params);
+  Counters total;
+  if (params->photons && !s->photons_built) build_photons(*s, *params, &total);  // BeginRender, RayTracer.cpp:29-38
+  const int tileSize = 32;  // raytracer.h:46
+  job.tiles_x = (job.k.W + tileSize - 1) / tileSize;
+  job.tiles_y = (job.k.H + tileSize - 1) / tileSize;
+  int total_tiles = job.tiles_x * job.tiles_y;
+  int stride = params->tile_stride > 0 ? params->tile_stride : 1;
+  for (int t = params->tile_begin, k = 0; t < total_tiles; t += stride, k++) {
+    if (params->tile_count > 0 && k >= params->tile_count) break;
+    job.tile_list.push_back(t);
+  }
+  if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();  // RayTracer.cpp:41
+  if (n_threads <= 0) n_threads = 1;
+  std::vector<Counters> cnts((size_t)n_threads);
+  std::vector<std::thread> threads;
+  for (int t = 0; t < n_threads; t++) threads.emplace_back(run_thread, &job, counters ? &cnts[t] : nullptr);
+  for (auto& th : threads) th.join();
+  for (auto& c : cnts) total.add(c);
+  if (counters) total.store(counters);
+  return RT_OK;
+}
+
+void orc_sample_radiance(orc_scene* s, const rt_render_params* params, int x, int y, int sample, float* out) {
+  CamConsts k = cam_consts(*s, *params);
+  int index = y * k.W + x;
+  PCG rng0;
+  float ro, roy;
+  pixel_offsets(*params, index, &rng0, ro, roy);
+  Sampler smp;
+  smp.mode = params->sampler;
+  smp.key[0] = params->seed_lo; smp.key[1] = params->seed_hi;
+  smp.pixel = (uint32_t)index;
+  PCG rng = rng0;
+  smp.pcg = &rng;
+  Ray ray = primary_ray(*s, *params, k, x, y, sample, ro, roy);
+  Color c = send_ray(*s, *params, sample, ray, x, y, k.W, k.H, smp, nullptr, nullptr);
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+void orc_primary_ray(const orc_scene* s, const rt_render_params* params, int x, int y, int sample, rt_ray* out) {
+  CamConsts k = cam_consts(*s, *params);
+  float ro, roy;
+  pixel_offsets(*params, y * k.W + x, nullptr, ro, roy);
+  Ray r = primary_ray(*s, *params, k, x, y, sample, ro, roy);
+  out->p[0] = r.p.x; out->p[1] = r.p.y; out->p[2] = r.p.z;
+  out->dir[0] = r.dir.x; out->dir[1] = r.dir.y; out->dir[2] = r.dir.z;
+}
+
+void orc_pcg32_seq(uint64_t sequence, uint64_t seed, int use_seed, int n, uint32_t* out_u32, float* out_f32) {
+  PCG r(sequence);
+  if (use_seed) r.set(sequence, seed);
+  for (int i = 0; i < n; i++) {
+    if (out_u32) out_u32[i] = r.next();
+    else if (out_f32) out_f32[i] = r.f();
+  }
+}
+float orc_halton(int index, int base) { return halton(index, base); }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox(ctr, key, out); }
+
+int orc_intersect_prim(int kind, const rt_ray* ray, int hit_side, rt_hit* hit) {
+  Ray r(from3(ray->p), from3(ray->dir));
+  Hit h;
+  bool ok = kind == RT_PRIM_SPHERE ? sphere_intersect(r, h, hit_side) : plane_intersect(r, h, hit_side);
+  hit_to_c(h, ok, hit);
+  return ok;
+}
+int orc_shadow_prim(int kind, const rt_ray* ray, float t_max) {
+  Ray r(from3(ray->p), from3(ray->dir));
+  return kind == RT_PRIM_SPHERE ? sphere_shadow(r, t_max) : plane_shadow(r, t_max);
+}
+int orc_hit_aabb(const rt_ray* ray, const float bounds[6]) {
+  Ray r(from3(ray->p), from3(ray->dir));
+  return hit_aabb(r, bounds);
+}
+void orc_eval_tex_color(const orc_scene* s, const rt_tex_color* tc, const float uvw[3], float out[3]) {
+  Color c = eval_tex_color(*s, *tc, from3(uvw), nullptr);
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void orc_eval_environment(const orc_scene* s, const rt_tex_color* tc, const float dir[3], float out[3]) {
+  Color c = eval_environment(*s, *tc, from3(dir), nullptr);
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+uint8_t orc_to_byte(float v) { return to_byte(v); }
+float orc_linear_to_srgb(float v) { return linear_to_srgb(v); }
+void orc_orthonormals(const float n[3], float t[3], float b[3]) {
+  V v0, v1;
+  orthonormals(from3(n), v0, v1);
+  t[0] = v0.x; t[1] = v0.y; t[2] = v0.z;
+  b[0] = v1.x; b[1] = v1.y; b[2] = v1.z;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""raytracer_amd — host-side mirror of the reference renderer API over the MI355X renderer core.
+
+`Renderer` keeps the names and argument meaning of the reference's `class Renderer`
+(reference RayTracer/renderer.h:209-238): LoadScene, BeginRender, StopRender, TraceRay,
+TraceShadowRay, GetPhotonMap, GetCausticsMap — so that the parity tests read like tests of the
+reference would.  All rendering goes through the C-ABI of librtcore.so (include/rtcore.h); there is
+no Python or CPU implementation of the hot path in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (RT_HIT_BACK, RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, RT_SAMPLER_PCG_HALTON, RT_SAMPLER_PHILOX,
+                   default_params, rt_counters, rt_framebuffer, rt_hit, rt_photon, rt_profile, rt_ray,
+                   rt_render_params, rt_scene_desc)
+
+__all__ = ["Scene", "Renderer", "RenderImage", "default_params", "rays_from_arrays", "hits_to_arrays",
+           "RT_HIT_FRONT", "RT_HIT_BACK", "RT_HIT_FRONT_AND_BACK", "RT_SAMPLER_PHILOX", "RT_SAMPLER_PCG_HALTON"]
+
+RAY_DTYPE = np.dtype([("p", np.float32, 3), ("dir", np.float32, 3)])
+HIT_DTYPE = np.dtype([("p", np.float32, 3), ("z", np.float32), ("N", np.float32, 3), ("uvw", np.float32, 3),
+                      ("node", np.int32), ("face", np.int32), ("light", np.int32), ("front", np.int32)])
+PHOTON_DTYPE = np.dtype([("position", np.float32, 3), ("power", np.float32), ("dir", np.float32, 3),
+                         ("color", np.uint8, 3), ("plane", np.uint8)])
+assert RAY_DTYPE.itemsize == C.sizeof(rt_ray) and HIT_DTYPE.itemsize == C.sizeof(rt_hit)
+assert PHOTON_DTYPE.itemsize == C.sizeof(rt_photon) == 32
+
+
+def rays_from_arrays(p, d):
+    r = np.zeros(len(p), dtype=RAY_DTYPE)
+    r["p"] = np.asarray(p, dtype=np.float32)
+    r["dir"] = np.asarray(d, dtype=np.float32)
+    return r
+
+
+def hits_to_arrays(h):
+    return {k: h[k] for k in HIT_DTYPE.names}
+
+
+class Scene:
+    """A loaded, flattened scene (host memory).  Mirrors what Renderer::LoadScene leaves behind
+    (reference RayTracer/xmlload.cpp:42-77): Scene + Camera."""
+
+    def __init__(self, handle):
+        self._host = _ffi.load_host()
+        if not handle:
+            raise RuntimeError("scene load failed: " + self._host.rth_last_error().decode())
+        self._h = C.c_void_p(handle)
+        self.desc_ptr = self._host.rth_scene_desc(self._h)
+        self.desc = self.desc_ptr.contents
+
+    @classmethod
+    def load(cls, path, asset_dir=None):
+        host = _ffi.load_host()
+        return cls(host.rth_scene_load_file(os.fsencode(path), os.fsencode(asset_dir) if asset_dir else None))
+
+    @classmethod
+    def from_string(cls, xml, asset_dir=None):
+        host = _ffi.load_host()
+        return cls(host.rth_scene_load_string(xml.encode(), os.fsencode(asset_dir) if asset_dir else None))
+
+    @classmethod
+    def stress(cls, seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160):
+        host = _ffi.load_host()
+        return cls(host.rth_scene_generate_stress(seed, n_instances, subdiv, ground_res, width, height))
+
+    @property
+    def warnings(self):
+        return self._host.rth_scene_warnings(self._h)
+
+    def node_name(self, i):
+        s = self._host.rth_scene_node_name(self._h, i)
+        return s.decode() if s is not None else None
+
+    @property
+    def width(self):
+        return self.desc.camera.width
+
+    @property
+    def height(self):
+        return self.desc.camera.height
+
+    def n_triangles(self):
+        return sum(self.desc.meshes[i].n_faces for i in range(self.desc.n_meshes))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._host.rth_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class RenderImage:
+    """Output buffers (reference RenderImage, RayTracer/renderer.h:35-103)."""
+
+    def __init__(self, w, h):
+        self.width, self.height = w, h
+        self.img = np.zeros((h, w, 3), np.uint8)
+        self.radiance = np.zeros((h, w, 4), np.float32)
+        self.sample_count = np.zeros((h, w), np.int32)
+        self.hit_node = np.full((h, w), -1, np.int32)
+        self.hit_face = np.full((h, w), -1, np.int32)
+
+    def framebuffer(self):
+        fb = rt_framebuffer()
+        fb.rgb8 = self.img.ctypes.data
+        fb.radiance = self.radiance.ctypes.data
+        fb.sample_count = self.sample_count.ctypes.data
+        fb.hit_node = self.hit_node.ctypes.data
+        fb.hit_face = self.hit_face.ctypes.data
+        fb.on_device = 0
+        return fb
+
+    def SaveImage(self, path):
+        host = _ffi.load_host()
+        return host.rth_write_png(os.fsencode(path), self.img.ctypes.data, self.width, self.height, 3) == 0
+
+
+class Renderer:
+    """Drop-in for the reference's RayTracer : Renderer (RayTracer/raytracer.h:14-61) on one MI355X."""
+
+    def __init__(self, device_id=0):
+        self._lib = _ffi.load_core()
+        ctx = C.c_void_p()
+        rc = self._lib.rt_context_create(device_id, C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"rt_context_create failed ({rc})")
+        self._ctx = ctx
+        self.scene = None
+        self.renderImage = None
+        self.params = default_params()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.rt_last_error(self._ctx)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- reference API -----------------------------------------------------------------
+    def LoadScene(self, path_or_scene, asset_dir=None):
+        self.scene = path_or_scene if isinstance(path_or_scene, Scene) else Scene.load(path_or_scene, asset_dir)
+        self._check(self._lib.rt_scene_commit(self._ctx, self.scene.desc_ptr), "rt_scene_commit")
+        return True
+
+    def _dims(self, params):
+        w = params.width if params.width > 0 else self.scene.width
+        h = params.height if params.height > 0 else self.scene.height
+        return w, h
+
+    def BeginRender(self, params=None):
+        params = params or self.params
+        w, h = self._dims(params)
+        self.renderImage = RenderImage(w, h)
+        self._fb = self.renderImage.framebuffer()
+        self._check(self._lib.rt_render_begin(self._ctx, C.byref(params), C.byref(self._fb)), "rt_render_begin")
+
+    def GetNumRenderedPixels(self):
+        done, fin = C.c_int64(), C.c_int()
+        self._check(self._lib.rt_render_poll(self._ctx, C.byref(done), C.byref(fin)), "rt_render_poll")
+        return done.value
+
+    def StopRender(self):
+        self._check(self._lib.rt_render_wait(self._ctx), "rt_render_wait")
+        return self.renderImage
+
+    def Render(self, params=None):
+        """Blocking BeginRender + StopRender."""
+        params = params or self.params
+        w, h = self._dims(params)
+        self.renderImage = RenderImage(w, h)
+        fb = self.renderImage.framebuffer()
+        self._check(self._lib.rt_render(self._ctx, C.byref(params), C.byref(fb)), "rt_render")
+        return self.renderImage
+
+    def TraceRay(self, rays, hitSide=RT_HIT_FRONT_AND_BACK):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self._check(self._lib.rt_trace_closest(self._ctx, rays.ctypes.data, len(rays), hitSide, hits.ctypes.data),
+                    "rt_trace_closest")
+        return hits
+
+    def TraceShadowRay(self, rays, t_max):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        t_max = np.ascontiguousarray(t_max, dtype=np.float32)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        self._check(self._lib.rt_trace_any(self._ctx, rays.ctypes.data, t_max.ctypes.data, len(rays), occ.ctypes.data),
+                    "rt_trace_any")
+        return occ.astype(bool)
+
+    def BuildPhotonMaps(self, params=None):
+        params = params or self.params
+        self._check(self._lib.rt_photons_build(self._ctx, C.byref(params)), "rt_photons_build")
+
+    def _photons(self, which, capacity=1 << 22):
+        out = np.zeros(capacity, dtype=PHOTON_DTYPE)
+        n = C.c_int32()
+        self._check(self._lib.rt_photons_download(self._ctx, which, out.ctypes.data, capacity, C.byref(n)),
+                    "rt_photons_download")
+        return out[:n.value].copy()
+
+    def GetPhotonMap(self):
+        return self._photons(0)
+
+    def GetCausticsMap(self):
+        return self._photons(1)
+
+    def EstimateIrradiance(self, which, P, N, radius=3.0, ellipticity=1.0, k=128):
+        P = np.ascontiguousarray(P, dtype=np.float32)
+        N = np.ascontiguousarray(N, dtype=np.float32)
+        out = np.zeros_like(P)
+        self._check(self._lib.rt_photon_gather(self._ctx, which, P.ctypes.data, N.ctypes.data, len(P), radius,
+                                               ellipticity, k, out.ctypes.data), "rt_photon_gather")
+        return out
+
+    def Denoise(self, rgb, albedo=None, normal=None):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        h, w = rgb.shape[:2]
+        out = np.zeros_like(rgb)
+        a = np.ascontiguousarray(albedo, np.float32) if albedo is not None else None
+        n = np.ascontiguousarray(normal, np.float32) if normal is not None else None
+        self._check(self._lib.rt_denoise(self._ctx, rgb.ctypes.data, out.ctypes.data, w, h,
+                                         a.ctypes.data if a is not None else None,
+                                         n.ctypes.data if n is not None else None), "rt_denoise")
+        return out
+
+    # -- multi-GPU / measurement helpers ---------------------------------------------------
+    def render_accumulate(self, params, d_accum_ptr):
+        self._check(self._lib.rt_render_accumulate(self._ctx, C.byref(params), C.c_void_p(d_accum_ptr)),
+                    "rt_render_accumulate")
+
+    def resolve(self, params, d_accum_ptr):
+        w, h = self._dims(params)
+        self.renderImage = RenderImage(w, h)
+        fb = self.renderImage.framebuffer()
+        self._check(self._lib.rt_resolve(self._ctx, C.byref(params), C.c_void_p(d_accum_ptr), C.byref(fb)), "rt_resolve")
+        return self.renderImage
+
+    def counters(self, enable=None, reset=False):
+        if enable is not None:
+            self._check(self._lib.rt_counters_enable(self._ctx, int(enable)), "rt_counters_enable")
+        if reset:
+            self._check(self._lib.rt_counters_reset(self._ctx), "rt_counters_reset")
+        c = rt_counters()
+        self._check(self._lib.rt_counters_get(self._ctx, C.byref(c)), "rt_counters_get")
+        return c.as_dict()
+
+    def profile(self, enable=None, reset=False):
+        if enable is not None:
+            self._check(self._lib.rt_profile_enable(self._ctx, int(enable)), "rt_profile_enable")
+        if reset:
+            self._check(self._lib.rt_profile_reset(self._ctx), "rt_profile_reset")
+        p = rt_profile()
+        self._check(self._lib.rt_profile_get(self._ctx, C.byref(p)), "rt_profile_get")
+        return {n: {"ms": p.ms[i], "launches": int(p.launches[i]), "items": int(p.items[i])}
+                for i, n in enumerate(_ffi.RT_K_NAMES)}
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.rt_context_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,160 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from raytracer_amd import HIT_DTYPE, PHOTON_DTYPE, RAY_DTYPE, RenderImage
+from raytracer_amd._ffi import rt_counters, rt_framebuffer, rt_hit, rt_ray, rt_render_params, rt_scene_desc, rt_tex_color
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+_lib = None
+_ref = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} missing: run `make -C oracle`")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.orc_scene_create.restype = vp
+    lib.orc_scene_create.argtypes = [C.POINTER(rt_scene_desc)]
+    lib.orc_scene_destroy.argtypes = [vp]
+    lib.orc_trace_closest.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    lib.orc_trace_any.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.orc_render.argtypes = [vp, C.POINTER(rt_render_params), C.POINTER(rt_framebuffer), C.c_int, C.POINTER(rt_counters)]
+    lib.orc_sample_radiance.argtypes = [vp, C.POINTER(rt_render_params), C.c_int, C.c_int, C.c_int, vp]
+    lib.orc_primary_ray.argtypes = [vp, C.POINTER(rt_render_params), C.c_int, C.c_int, C.c_int, C.POINTER(rt_ray)]
+    lib.orc_photons_build.argtypes = [vp, C.POINTER(rt_render_params), C.POINTER(rt_counters)]
+    lib.orc_photons_count.argtypes = [vp, C.c_int]
+    lib.orc_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32]
+    lib.orc_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
+    lib.orc_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
+    lib.orc_pcg32_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp]
+    lib.orc_halton.restype = C.c_float
+    lib.orc_halton.argtypes = [C.c_int, C.c_int]
+    lib.orc_philox4x32_10.argtypes = [vp, vp, vp]
+    lib.orc_intersect_prim.argtypes = [C.c_int, C.POINTER(rt_ray), C.c_int, C.POINTER(rt_hit)]
+    lib.orc_shadow_prim.argtypes = [C.c_int, C.POINTER(rt_ray), C.c_float]
+    lib.orc_hit_aabb.argtypes = [C.POINTER(rt_ray), vp]
+    lib.orc_eval_tex_color.argtypes = [vp, C.POINTER(rt_tex_color), vp, vp]
+    lib.orc_eval_environment.argtypes = [vp, C.POINTER(rt_tex_color), vp, vp]
+    lib.orc_to_byte.restype = C.c_uint8
+    lib.orc_to_byte.argtypes = [C.c_float]
+    lib.orc_linear_to_srgb.restype = C.c_float
+    lib.orc_linear_to_srgb.argtypes = [C.c_float]
+    lib.orc_orthonormals.argtypes = [vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def load_ref_rng():
+    """oracle/_ref/librefrng.so: the reference's own rng.h compiled unmodified (None if not built)."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    path = os.path.join(ORACLE_DIR, "_ref", "librefrng.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.ref_pcg32_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ref_halton.restype = C.c_float
+    lib.ref_halton.argtypes = [C.c_int, C.c_int]
+    lib.ref_halton_seq128.argtypes = [C.c_int, C.c_void_p]
+    _ref = lib
+    return lib
+
+
+class OracleScene:
+    def __init__(self, scene):
+        self.lib = load()
+        self.scene = scene  # keeps host memory alive
+        self.h = C.c_void_p(self.lib.orc_scene_create(scene.desc_ptr))
+        if not self.h:
+            raise RuntimeError("orc_scene_create failed")
+
+    def trace_closest(self, rays, hit_side=3):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self.lib.orc_trace_closest(self.h, rays.ctypes.data, len(rays), hit_side, hits.ctypes.data)
+        return hits
+
+    def trace_any(self, rays, t_max):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        t_max = np.ascontiguousarray(t_max, dtype=np.float32)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        self.lib.orc_trace_any(self.h, rays.ctypes.data, t_max.ctypes.data, len(rays), occ.ctypes.data)
+        return occ.astype(bool)
+
+    def render(self, params, n_threads=0, want_counters=False):
+        w = params.width if params.width > 0 else self.scene.width
+        h = params.height if params.height > 0 else self.scene.height
+        img = RenderImage(w, h)
+        fb = img.framebuffer()
+        cnt = rt_counters()
+        rc = self.lib.orc_render(self.h, C.byref(params), C.byref(fb), n_threads, C.byref(cnt) if want_counters else None)
+        if rc != 0:
+            raise RuntimeError(f"orc_render failed ({rc})")
+        if want_counters:
+            return img, cnt.as_dict()
+        return img
+
+    def sample_radiance(self, params, x, y, sample):
+        out = np.zeros(3, np.float32)
+        self.lib.orc_sample_radiance(self.h, C.byref(params), x, y, sample, out.ctypes.data)
+        return out
+
+    def primary_ray(self, params, x, y, sample):
+        r = rt_ray()
+        self.lib.orc_primary_ray(self.h, C.byref(params), x, y, sample, C.byref(r))
+        return np.array(r.p[:], np.float32), np.array(r.dir[:], np.float32)
+
+    def photons_build(self, params):
+        return self.lib.orc_photons_build(self.h, C.byref(params), None)
+
+    def photons(self, which):
+        n = self.lib.orc_photons_count(self.h, which)
+        out = np.zeros(max(n, 1), dtype=PHOTON_DTYPE)
+        n = self.lib.orc_photons_download(self.h, which, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def photons_set(self, which, photons):
+        photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+        self.lib.orc_photons_set(self.h, which, photons.ctypes.data, len(photons))
+
+    def photon_gather(self, which, P, N, radius=3.0, ellipticity=1.0, k=128):
+        P = np.ascontiguousarray(P, dtype=np.float32)
+        N = np.ascontiguousarray(N, dtype=np.float32)
+        out = np.zeros_like(P)
+        self.lib.orc_photon_gather(self.h, which, P.ctypes.data, N.ctypes.data, len(P), radius, ellipticity, k,
+                                   out.ctypes.data)
+        return out
+
+    def eval_tex_color(self, tc, uvw):
+        out = np.zeros(3, np.float32)
+        uvw = np.ascontiguousarray(uvw, np.float32)
+        self.lib.orc_eval_tex_color(self.h, C.byref(tc), uvw.ctypes.data, out.ctypes.data)
+        return out
+
+    def eval_environment(self, tc, d):
+        out = np.zeros(3, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        self.lib.orc_eval_environment(self.h, C.byref(tc), d.ctypes.data, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.orc_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
