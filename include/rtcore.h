@@ -211,6 +211,8 @@ typedef struct rt_counters {
   uint64_t inst_tests, sphere_tests, plane_tests, node_visits, tri_tests;
   uint64_t shades, tex_evals, photon_visits, gathers;
   uint64_t paths;
+  /* the share of inst_tests / node_visits / tri_tests done by the closest-hit kernel (roofline attribution) */
+  uint64_t closest_inst_tests, closest_node_visits, closest_tri_tests;
 } rt_counters;
 
 enum { RT_K_RAYGEN = 0, RT_K_TRACE_CLOSEST, RT_K_SHADE, RT_K_SHADOW, RT_K_ACCUM, RT_K_PHOTON_TRACE, RT_K_PHOTON_GATHER, RT_K_DENOISE, RT_K_COUNT };

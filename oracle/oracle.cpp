@@ -210,6 +210,7 @@ struct Counters {
     c->rays_photon = rays_photon; c->inst_tests = inst_tests; c->sphere_tests = sphere_tests;
     c->plane_tests = plane_tests; c->node_visits = node_visits; c->tri_tests = tri_tests; c->shades = shades;
     c->tex_evals = tex_evals; c->photon_visits = photon_visits; c->gathers = gathers; c->paths = paths;
+    c->closest_inst_tests = c->closest_node_visits = c->closest_tri_tests = 0;
   }
 };
 

@@ -123,8 +123,10 @@ class RenderImage:
 class Renderer:
     """Drop-in for the reference's RayTracer : Renderer (RayTracer/raytracer.h:14-61) on one MI355X."""
 
-    def __init__(self, device_id=0):
-        self._lib = _ffi.load_core()
+    def __init__(self, device_id=0, _lib=None):
+        # _lib: tests pass the host-emulation build of the same sources (tests/_emu); the package itself only
+        # ever loads librtcore.so and raises if it is missing.
+        self._lib = _lib if _lib is not None else _ffi.load_core()
         ctx = C.c_void_p()
         rc = self._lib.rt_context_create(device_id, C.byref(ctx))
         if rc != 0:

@@ -113,7 +113,8 @@ class rt_framebuffer(C.Structure):
 class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("rays_primary", "rays_secondary", "rays_shadow", "rays_photon", "inst_tests", "sphere_tests",
-                 "plane_tests", "node_visits", "tri_tests", "shades", "tex_evals", "photon_visits", "gathers", "paths")]
+                 "plane_tests", "node_visits", "tri_tests", "shades", "tex_evals", "photon_visits", "gathers", "paths",
+                 "closest_inst_tests", "closest_node_visits", "closest_tri_tests")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -208,7 +209,35 @@ def load_core():
     path = os.path.join(LIB_DIR, "librtcore.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension must be built (no CPU fallback exists)")
-    lib = C.CDLL(path)
+    _preload_torch_hip_runtime()
+    _core = bind_core(C.CDLL(path))
+    return _core
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as
+    /opt/rocm's); if librtcore.so pulled in /opt/rocm's copy first, a later `import torch` would bring a second
+    runtime and fail with "No HIP GPUs are available".  So when torch is installed, its copy is loaded first and
+    librtcore.so binds to it (torch itself is not imported here)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
+def bind_core(lib):
+    """Declares the C-ABI signatures of include/rtcore.h on a loaded library object."""
     vp = C.c_void_p
     lib.rt_context_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.rt_context_destroy.argtypes = [vp]
@@ -235,5 +264,4 @@ def load_core():
     lib.rt_profile_get.argtypes = [vp, C.POINTER(rt_profile)]
     lib.rt_render_params_default.argtypes = [C.POINTER(rt_render_params)]
     lib.rt_render_params_default.restype = None
-    _core = lib
     return lib

@@ -1,0 +1,699 @@
+// Device-side data layout and leaf routines of the renderer core (gfx950).
+//
+// Arithmetic notes.  Everything is FP32, compiled with -ffp-contract=off; division and sqrt are
+// IEEE (hipcc default), so intersection decisions reproduce the reference's C++ expressions
+// operation for operation (reference files cited per routine, relative to RayTracer/).
+#pragma once
+#include <float.h>
+#include <math.h>
+
+#include "rt_platform.h"
+
+#define RT_BIG FLT_MAX            // BIGFLOAT, scene.h:34
+#define RT_MAX_CHAIN 8            // maximum scene-graph depth of an instanced primitive
+#define RT_STACK 32               // BVH traversal stack entries per lane (builder guarantees depth <= 32)
+#define RT_LEAF 0x80000000u
+#define RT_PI_F 3.14159265358979323846f
+#define RT_PI_D 3.14159265358979323846
+
+struct V3 {
+  float x, y, z;
+};
+RT_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RT_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+RT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_HD float length(V3 a) { return sqrtf(dot(a, a)); }
+RT_HD V3 normalized(V3 a) { return a / length(a); }
+RT_HD bool nonzero(V3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
+
+// ------------------------------------------------------------------ device scene
+
+struct DNode {          // one scene-graph node: Transformation::itm / tm (scene.h:155-156), column-major 3x4
+  float itm[12];
+  float tm[12];
+};
+
+struct DInstance {      // a node that carries a primitive, with its chain of ancestors
+  int32_t node;         // node index (== rt_node index)
+  int32_t prim;         // RT_PRIM_*
+  int32_t mesh;
+  int32_t mtl;          // material index; n_materials = the default Blinn
+  int32_t depth;        // number of entries in chain
+  int32_t chain[RT_MAX_CHAIN];  // node indices root .. this node
+  float wmin[3], wmax[3];       // padded world-space bounds (culling of mesh instances only)
+};
+
+struct DMesh {
+  uint32_t node_base;   // float4 index of this mesh's first 64-byte BVH node in DScene::bvh
+  uint32_t tri_base;    // float4 index of this mesh's first 48-byte triangle slot in DScene::tris
+  uint32_t nrm_base, nidx_base, uvw_base, uidx_base;  // element offsets into the attribute arrays
+  uint32_t root_ref;    // child reference of the root (leaf bit | first_slot<<3 | count, or internal node index)
+  uint32_t has_uvw;
+  float bounds[6];      // root box: min xyz, max xyz
+};
+
+struct DTexColor { float v[3]; int32_t map; };
+struct DTexFloat { float v; int32_t map; };
+struct DTexmap {
+  int32_t kind, image;
+  float itm[12];
+  DTexColor color[2];
+};
+struct DImage { uint32_t offset; int32_t width, height; int32_t pad; };
+struct DMaterial {
+  int32_t kind;
+  DTexColor diffuse, specular, emission, reflection, refraction;
+  DTexFloat glossiness;
+  float absorption[3];
+  float ior;
+};
+struct DLight {
+  int32_t kind;
+  float intensity[3], position[3], direction[3];
+  float size, attenuation;
+};
+
+struct DScene {
+  const DNode* nodes;
+  const DInstance* inst;
+  const DMesh* meshes;
+  const float4* bvh;
+  const float4* tris;
+  const float* normals;
+  const uint32_t* nrm_idx;
+  const float* uvw;
+  const uint32_t* uvw_idx;
+  const DMaterial* materials;
+  const DTexmap* texmaps;
+  const DImage* images;
+  const uint8_t* texels;
+  const DLight* lights;
+  const float* halton;  // [0,128) base 2, [128,256) base 3, [256,384) base 5, [384,512) base 7, then 1000 base 2,
+                        // 1000 base 3 (HaltonSeq<1000>), then n_gloss base 2 and n_gloss base 3 (Halton(i, b) direct)
+  int32_t n_inst, n_lights, n_materials, n_gloss;
+  DTexColor background, environment;
+};
+#define RT_H2 0
+#define RT_H3 128
+#define RT_H5 256
+#define RT_H7 384
+#define RT_HPHI 512
+#define RT_HTHETA 1512
+#define RT_HGLOSS 2512
+
+struct DCounters {  // mirrors rt_counters
+  unsigned long long rays_primary, rays_secondary, rays_shadow, rays_photon;
+  unsigned long long inst_tests, sphere_tests, plane_tests, node_visits, tri_tests;
+  unsigned long long shades, tex_evals, photon_visits, gathers, paths;
+  unsigned long long closest_inst_tests, closest_node_visits, closest_tri_tests;
+};
+
+// per-lane work counters kept in registers by the counted kernel variants
+struct LaneCnt {
+  uint32_t inst, sphere, plane, node, tri, tex;
+};
+template <bool CNT> struct Cnt;
+template <> struct Cnt<true> {
+  LaneCnt c;
+  RT_MEM Cnt() { c.inst = c.sphere = c.plane = c.node = c.tri = c.tex = 0; }
+  RT_MEM void inst(uint32_t n = 1) { c.inst += n; }
+  RT_MEM void sphere() { c.sphere++; }
+  RT_MEM void plane() { c.plane++; }
+  RT_MEM void node(uint32_t n = 1) { c.node += n; }
+  RT_MEM void tri() { c.tri++; }
+  RT_MEM void tex() { c.tex++; }
+  RT_MEM void flush(DCounters* g) {
+    if (c.inst) rt_atomic_add_u64(&g->inst_tests, c.inst);
+    if (c.sphere) rt_atomic_add_u64(&g->sphere_tests, c.sphere);
+    if (c.plane) rt_atomic_add_u64(&g->plane_tests, c.plane);
+    if (c.node) rt_atomic_add_u64(&g->node_visits, c.node);
+    if (c.tri) rt_atomic_add_u64(&g->tri_tests, c.tri);
+    if (c.tex) rt_atomic_add_u64(&g->tex_evals, c.tex);
+  }
+  RT_MEM void flush_closest(DCounters* g) {
+    if (c.inst) rt_atomic_add_u64(&g->closest_inst_tests, c.inst);
+    if (c.node) rt_atomic_add_u64(&g->closest_node_visits, c.node);
+    if (c.tri) rt_atomic_add_u64(&g->closest_tri_tests, c.tri);
+  }
+};
+template <> struct Cnt<false> {
+  RT_MEM void inst(uint32_t = 1) {}
+  RT_MEM void sphere() {}
+  RT_MEM void plane() {}
+  RT_MEM void node(uint32_t = 1) {}
+  RT_MEM void tri() {}
+  RT_MEM void tex() {}
+  RT_MEM void flush(DCounters*) {}
+  RT_MEM void flush_closest(DCounters*) {}
+};
+
+// ------------------------------------------------------------------ transforms (scene.h:170-189)
+RT_HD V3 xf_point(const float* m, V3 p) {
+  return v3(m[0] * p.x + m[3] * p.y + m[6] * p.z + m[9], m[1] * p.x + m[4] * p.y + m[7] * p.z + m[10],
+            m[2] * p.x + m[5] * p.y + m[8] * p.z + m[11]);
+}
+RT_HD V3 xf_dir(const float* m, V3 p) {
+  return v3(m[0] * p.x + m[3] * p.y + m[6] * p.z, m[1] * p.x + m[4] * p.y + m[7] * p.z,
+            m[2] * p.x + m[5] * p.y + m[8] * p.z);
+}
+RT_HD V3 xf_tmul(const float* m, V3 p) {  // (3x3)^T * p : NormalTransformFrom with itm
+  return v3(m[0] * p.x + m[1] * p.y + m[2] * p.z, m[3] * p.x + m[4] * p.y + m[5] * p.z,
+            m[6] * p.x + m[7] * p.y + m[8] * p.z);
+}
+
+// GetOrthonormals as this build defines it (see oracle.cpp `orthonormals`)
+RT_HD void orthonormals(V3 n, V3& v0, V3& v1) {
+  if (n.z >= n.y) {
+    float a = 1.0f / (1.0f + n.z);
+    float b = -n.x * n.y * a;
+    v0 = v3(1.0f - n.x * n.x * a, b, -n.x);
+    v1 = v3(b, 1.0f - n.y * n.y * a, -n.y);
+  } else {
+    float a = 1.0f / (1.0f + n.y);
+    float b = -n.z * n.x * a;
+    v0 = v3(b, -n.z, 1.0f - n.z * n.z * a);
+    v1 = v3(1.0f - n.x * n.x * a, -n.x, b);
+  }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 / sampling
+RT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+RT_HD float u32_to_unit(uint32_t u) {  // RNG::RandomFloat mapping, rng.h:60-65
+  const float rmax = 0x1.fffffep-1f;
+  float r = (float)u * 0x1p-32f;
+  return r < rmax ? r : rmax;
+}
+#define RT_TAG_PIXEL 0u
+#define RT_TAG_SHADE 1u
+#define RT_TAG_PHOTON 2u
+
+// ------------------------------------------------------------------ primitives
+
+// Sphere::IntersectRay, objects.cpp:20-61 — decision part; attributes are filled once at the end.
+RT_DEV bool sphere_closest(V3 p, V3 d, int hitSide, float& t, bool& front) {
+  const float eps = 0.002f;
+  float a = dot(d, d);
+  float b = 2.0f * dot(d, p);
+  float c = dot(p, p) - 1.0f;
+  float disc = b * b - 4.0f * a * c;
+  if (disc < 0.0f) return false;
+  float sq = sqrtf(disc);
+  float twoA = 2.0f * a;
+  float t1 = (-b - sq) / twoA;
+  float t2 = (-b + sq) / twoA;
+  if (t1 > eps && (hitSide & 1)) {
+    t = t1; front = true; return true;
+  } else if (t2 >= eps && (hitSide & 2)) {
+    t = t2; front = false; return true;
+  }
+  return false;
+}
+// Sphere::ShadowRay, objects.cpp:63-82 (the reference compares against the double 0.01; for float t that is
+// the same set as t > 0.01f because 0.01f < 0.01 < nextafter(0.01f))
+RT_DEV bool sphere_any(V3 p, V3 d, float t_max) {
+  float a = dot(d, d);
+  float b = 2.0f * dot(d, p);
+  float c = dot(p, p) - 1.0f;
+  float disc = b * b - 4.0f * a * c;
+  if (disc < 0.0f) return false;
+  float sq = sqrtf(disc);
+  float twoA = 2.0f * a;
+  float t1 = (-b - sq) / twoA;
+  float t2 = (-b + sq) / twoA;
+  if (t1 > 0.01f && t1 < t_max) return true;
+  if (t2 > 0.01f && t2 < t_max) return true;
+  return false;
+}
+// Plane::IntersectRay, objects.cpp:126-150 (0.0002 double vs float: same argument as above)
+RT_DEV bool plane_closest(V3 p, V3 d, int hitSide, float& t, bool& front) {
+  if (fabsf(d.z) < 1e-8f) return false;
+  float tt = -(p.z / d.z);
+  if (tt > 0.0002f) {
+    float hx = p.x + d.x * tt, hy = p.y + d.y * tt;
+    if (hx < -1.0f || hx > 1.0f || hy < -1.0f || hy > 1.0f) return false;
+    bool f = (d.x * 0.0f + d.y * 0.0f + d.z * 1.0f) < 0.0f;
+    if ((f && (hitSide & 1)) || (!f && (hitSide & 2))) {
+      t = tt; front = f; return true;
+    }
+  }
+  return false;
+}
+// Plane::ShadowRay, objects.cpp:152-167
+RT_DEV bool plane_any(V3 p, V3 d, float t_max) {
+  float t = -(p.z / d.z);
+  if (t > 0.0002f && t < t_max) {
+    float hx = p.x + d.x * t, hy = p.y + d.y * t;
+    if (hx < -1.0f || hx > 1.0f || hy < -1.0f || hy > 1.0f) return false;
+    return true;
+  }
+  return false;
+}
+
+// hitAABB, objects.cpp:94-120, returning also the entry parameter.  The ternaries keep FAST_MIN/FAST_MAX's
+// behaviour for NaN operands (0 * inf when a ray lies in a slab plane).
+#define RT_FMIN(a, b) ((a) < (b) ? (a) : (b))
+#define RT_FMAX(a, b) ((a) > (b) ? (a) : (b))
+RT_DEV bool box_test(V3 p, V3 inv, float b0, float b1, float b2, float b3, float b4, float b5, float& tmin_out) {
+  float t1 = (b0 - p.x) * inv.x;
+  float t2 = (b3 - p.x) * inv.x;
+  float t3 = (b1 - p.y) * inv.y;
+  float t4 = (b4 - p.y) * inv.y;
+  float t5 = (b2 - p.z) * inv.z;
+  float t6 = (b5 - p.z) * inv.z;
+  float tminX = RT_FMIN(t1, t2), tmaxX = RT_FMAX(t1, t2);
+  float tminY = RT_FMIN(t3, t4), tmaxY = RT_FMAX(t3, t4);
+  float tminZ = RT_FMIN(t5, t6), tmaxZ = RT_FMAX(t5, t6);
+  float tmin = RT_FMAX(RT_FMAX(tminX, tminY), tminZ);
+  float tmax = RT_FMIN(RT_FMIN(tmaxX, tmaxY), tmaxZ);
+  tmin_out = tmin;
+  return tmax >= tmin && tmax >= 0.0f;
+}
+
+// Möller–Trumbore with precomputed edges — TriObj::IntersectTriangle, objects.cpp:193-231.
+// (v0, e1 = v1 - v0, e2 = v2 - v0) are the same float values the reference computes per test.
+RT_DEV bool tri_test(V3 p, V3 d, V3 v0, V3 e1, V3 e2, float& t, float& u, float& v) {
+  const float epsilon = 0.002f;
+  V3 h = cross(d, e2);
+  float det = dot(e1, h);
+  if (fabsf(det) < epsilon) return false;
+  float inv_det = 1.0f / det;
+  V3 s = p - v0;
+  float uu = inv_det * dot(s, h);
+  if (uu < 0.0f || uu > 1.0f) return false;
+  V3 q = cross(s, e1);
+  float vv = inv_det * dot(d, q);
+  if (vv < 0.0f || (uu + vv) > 1.0f) return false;
+  float tt = inv_det * dot(e2, q);
+  t = tt; u = uu; v = vv;
+  return true;
+}
+
+// Pruning slack: a BVH box is skipped only when its entry parameter exceeds the best hit by more than the
+// rounding the slab test and Möller–Trumbore can disagree by; the reference prunes nothing (objects.cpp:268-339),
+// so skipping must never hide a triangle that would have won.
+RT_DEV float prune_bound(float t) { return t + (fabsf(t) * 1e-4f + 1e-4f); }
+
+struct MeshHit {
+  float t, u, v;
+  uint32_t key;   // leaf order * 4 + (3 - slot in leaf): reproduces the reference's tie-breaks
+  uint32_t face;
+};
+
+// Closest hit inside one mesh.  Equivalent to TriObj::TraceBVHNode (objects.cpp:268-339): the result is the
+// minimum-t triangle among all leaves whose chain of boxes the ray's line hits; on equal t the later leaf in
+// depth-first order wins (child 2 beats child 1, :331-337) and inside a leaf the earlier triangle wins (:294).
+// Traversal is ordered and pruned against `t_bound` (hits at or beyond the current global best cannot win:
+// the scene-graph compare is a strict <, RayTracer.cpp:387,404).
+template <bool CNT>
+RT_DEV bool mesh_closest(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_bound, MeshHit& out,
+                         uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  float tm;
+  cnt.node();
+  if (!box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
+  const float4* nodes = S.bvh + M.node_base;
+  const float4* tris = S.tris + M.tri_base;
+  float best_t = RT_BIG;
+  uint32_t best_key = 0, best_face = 0;
+  float best_u = 0, best_v = 0;
+  bool found = false;
+  uint32_t cur = M.root_ref;
+  int sp = 0;
+  for (;;) {
+    if (cur & RT_LEAF) {
+      uint32_t count = cur & 7u, first = (cur & 0x7fffffffu) >> 3;
+      for (uint32_t s = 0; s < count; s++) {
+        float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+        float t, u, v;
+        cnt.tri();
+        if (tri_test(p, d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+          if (t > 0.002f) {
+            uint32_t key = __float_as_uint(a.w);
+            if (t < best_t || (t == best_t && found && key > best_key)) {
+              best_t = t; best_key = key; best_face = __float_as_uint(b.w); best_u = u; best_v = v; found = true;
+            }
+          }
+        }
+      }
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+    float tl, tr;
+    cnt.node(2);
+    bool hl = box_test(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+    bool hr = box_test(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+    float bound = prune_bound(best_t < t_bound ? best_t : t_bound);
+    hl = hl && tl <= bound;
+    hr = hr && tr <= bound;
+    uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+    if (hl && hr) {
+      bool left_first = tl <= tr;
+      uint32_t nearc = left_first ? cl : cr, farc = left_first ? cr : cl;
+      stk[(sp++) * stride] = farc;
+      cur = nearc;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+    }
+  }
+  if (!found) return false;
+  out.t = best_t; out.u = best_u; out.v = best_v; out.key = best_key; out.face = best_face;
+  return true;
+}
+
+// TriObj::TraceBVHNodeShadow (objects.cpp:341-371): true iff some triangle of a visited leaf has t in (0.002, t_max).
+template <bool CNT>
+RT_DEV bool mesh_any(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_max, uint32_t* stk, uint32_t stride,
+                     Cnt<CNT>& cnt) {
+  float tm;
+  cnt.node();
+  if (!box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
+  const float4* nodes = S.bvh + M.node_base;
+  const float4* tris = S.tris + M.tri_base;
+  float bound = prune_bound(t_max);
+  uint32_t cur = M.root_ref;
+  int sp = 0;
+  for (;;) {
+    if (cur & RT_LEAF) {
+      uint32_t count = cur & 7u, first = (cur & 0x7fffffffu) >> 3;
+      for (uint32_t s = 0; s < count; s++) {
+        float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+        float t, u, v;
+        cnt.tri();
+        if (tri_test(p, d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
+          if (t > 0.002f && t < t_max) return true;
+      }
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+    float tl, tr;
+    cnt.node(2);
+    bool hl = box_test(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl) && tl <= bound;
+    bool hr = box_test(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr) && tr <= bound;
+    uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+    if (hl && hr) {
+      stk[(sp++) * stride] = cr;
+      cur = cl;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+    }
+  }
+  return false;
+}
+
+// PointLight::IntersectRay, objects.cpp:377-413 (int radius, double arithmetic)
+RT_DEV bool light_sphere(const DLight& L, V3 p, V3 d, float zbest, float& t_out, bool& front) {
+  int r = (int)L.size;
+  V3 oc = p - v3(L.position[0], L.position[1], L.position[2]);
+  float eps = 0.002f;
+  double a = (double)dot(d, d);
+  double b = 2.0 * (double)dot(oc, d);
+  double c = (double)(dot(oc, oc) - (float)(r * r));
+  double disc = b * b - 4 * a * c;
+  if (disc < 0) return false;
+  float sq = sqrtf((float)disc);
+  float twoA = (float)(2 * a);
+  double t1 = (-b - (double)sq) / (double)twoA;
+  double t2 = (-b + (double)sq) / (double)twoA;
+  // hInfo.z of the fresh HitInfo is BIGFLOAT, so `hInfo.z > t` holds for every finite t
+  if (t1 > (double)eps) {
+    if ((double)RT_BIG > t1) { t_out = (float)t1; front = true; return true; }
+  } else if (t2 >= (double)eps) {
+    if ((double)RT_BIG > t2) { t_out = (float)t2; front = false; return true; }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ scene traversal
+
+struct Hit {            // HitInfo (scene.h:74-90) in world space before SetHit
+  V3 p;
+  float z;
+  V3 N;
+  V3 uvw;
+  int32_t inst;         // instance index, -1 none
+  int32_t face;
+  int32_t light;        // -1 or light index
+  bool front;
+};
+
+RT_DEV void ray_to_instance(const DScene& S, const DInstance& I, V3& p, V3& d) {
+  for (int k = 0; k < I.depth; k++) {  // Node::ToNodeCoords down the chain (RayTracer.cpp:377)
+    const float* itm = S.nodes[I.chain[k]].itm;
+    V3 np = xf_point(itm, p);
+    V3 nd = xf_dir(itm, d);
+    p = np; d = nd;
+  }
+}
+
+// Renderer::TraceRay -> RayTracer::TraverseTree (RayTracer.cpp:373-435): closest hit over every instanced
+// primitive in depth-first node order with strict '<', then the renderable lights.
+template <bool CNT>
+RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  float best_t = RT_BIG;
+  int best_inst = -1;
+  bool best_front = true;
+  MeshHit best_mh;
+  best_mh.t = 0; best_mh.u = 0; best_mh.v = 0; best_mh.key = 0; best_mh.face = 0;
+  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  for (int i = 0; i < S.n_inst; i++) {
+    const DInstance& I = S.inst[i];
+    if (I.prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
+      float tm;         // hit the mesh, so the result is unchanged)
+      if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    }
+    V3 p = o, d = dir;
+    ray_to_instance(S, I, p, d);
+    cnt.inst();
+    float t;
+    bool front;
+    if (I.prim == 1) {
+      cnt.sphere();
+      if (sphere_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
+    } else if (I.prim == 2) {
+      cnt.plane();
+      if (plane_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
+    } else if (I.prim == 3) {
+      V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      MeshHit mh;
+      if (mesh_closest<CNT>(S, S.meshes[I.mesh], p, d, inv, best_t, mh, stk, stride, cnt) && mh.t < best_t) {
+        best_t = mh.t; best_inst = i; best_mh = mh;
+      }
+    }
+  }
+  hit.inst = -1; hit.face = -1; hit.light = -1; hit.front = true; hit.z = RT_BIG;
+  hit.p = v3(0, 0, 0); hit.N = v3(0, 0, 0); hit.uvw = v3(0.5f, 0.5f, 0.5f);
+  bool any = false;
+  if (best_inst >= 0) {
+    any = true;
+    const DInstance& I = S.inst[best_inst];
+    V3 p = o, d = dir;
+    ray_to_instance(S, I, p, d);
+    V3 hp, hn, uvw;
+    bool front = best_front;
+    if (I.prim == 1) {  // objects.cpp:37-43
+      hp = p + (d * best_t);
+      hn = normalized(hp);
+      float tu = (float)(((double)atan2f(hp.y, hp.x) / (2 * RT_PI_D)) + .5);
+      float tv = (float)((double)asinf(hp.z) / RT_PI_D + .5);
+      uvw = v3(tu, tv, 0.0f);
+    } else if (I.prim == 2) {  // objects.cpp:135-138
+      hp = p + (d * best_t);
+      hn = v3(0.0f, 0.0f, 1.0f);
+      uvw = v3((hp.x + 1.0f) * 0.5f, (hp.y + 1.0f) * 0.5f, 0.0f);
+    } else {  // objects.cpp:303-320
+      const DMesh& M = S.meshes[I.mesh];
+      float u = best_mh.u, v = best_mh.v, w = 1.0f - u - v;
+      uvw = v3(0, 0, 0);
+      if (M.has_uvw) {
+        const uint32_t* ft = S.uvw_idx + M.uidx_base + 3 * best_mh.face;
+        const float* t0 = S.uvw + M.uvw_base + 3 * ft[0];
+        const float* t1 = S.uvw + M.uvw_base + 3 * ft[1];
+        const float* t2 = S.uvw + M.uvw_base + 3 * ft[2];
+        uvw = (v3(t0[0], t0[1], t0[2]) * w) + (v3(t1[0], t1[1], t1[2]) * u) + (v3(t2[0], t2[1], t2[2]) * v);
+      }
+      const uint32_t* fn = S.nrm_idx + M.nidx_base + 3 * best_mh.face;
+      const float* n0 = S.normals + M.nrm_base + 3 * fn[0];
+      const float* n1 = S.normals + M.nrm_base + 3 * fn[1];
+      const float* n2 = S.normals + M.nrm_base + 3 * fn[2];
+      hn = normalized(w * v3(n0[0], n0[1], n0[2]) + u * v3(n1[0], n1[1], n1[2]) + v * v3(n2[0], n2[1], n2[2]));
+      hp = p + d * best_t;
+      front = dot(d, hn) < 0.0f;
+      hit.face = (int32_t)best_mh.face;
+    }
+    for (int k = I.depth - 1; k >= 0; k--) {  // Node::FromNodeCoords back up the chain (scene.h:184-189)
+      const DNode& n = S.nodes[I.chain[k]];
+      hp = xf_point(n.tm, hp);
+      hn = xf_tmul(n.itm, hn);
+    }
+    hit.p = hp; hit.N = hn; hit.uvw = uvw; hit.z = best_t; hit.inst = best_inst; hit.front = front;
+  }
+  for (int l = 0; l < S.n_lights; l++) {  // RayTracer.cpp:413-432
+    const DLight& L = S.lights[l];
+    if (L.kind == 3 && L.size > 0.0f) {
+      float t;
+      bool front;
+      if (light_sphere(L, o, dir, RT_BIG, t, front)) {
+        if (t < hit.z) {
+          hit.z = t;
+          hit.p = o + (dir * t);
+          hit.N = v3(0, 0, 0);
+          hit.uvw = v3(0.5f, 0.5f, 0.5f);
+          hit.inst = -1; hit.face = -1; hit.light = l; hit.front = front;
+          any = true;
+        }
+      }
+    }
+  }
+  return any;
+}
+
+// Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
+template <bool CNT>
+RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  for (int i = 0; i < S.n_inst; i++) {
+    const DInstance& I = S.inst[i];
+    if (I.prim == 3) {
+      float tm;
+      if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    }
+    V3 p = o, d = dir;
+    ray_to_instance(S, I, p, d);
+    cnt.inst();
+    if (I.prim == 1) {
+      cnt.sphere();
+      if (sphere_any(p, d, t_max)) return true;
+    } else if (I.prim == 2) {
+      cnt.plane();
+      if (plane_any(p, d, t_max)) return true;
+    } else if (I.prim == 3) {
+      V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      if (mesh_any<CNT>(S, S.meshes[I.mesh], p, d, inv, t_max, stk, stride, cnt)) return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ textures (texture.cpp:106-140, scene.h:312-397)
+RT_DEV V3 tile_clamp(V3 uvw) {
+  V3 u;
+  u.x = uvw.x - (float)(int)uvw.x;
+  u.y = uvw.y - (float)(int)uvw.y;
+  u.z = uvw.z - (float)(int)uvw.z;
+  if (u.x < 0) u.x += 1;
+  if (u.y < 0) u.y += 1;
+  if (u.z < 0) u.z += 1;
+  return u;
+}
+RT_DEV V3 image_eval(const DScene& S, const DImage& im, V3 uvw) {
+  int width = im.width, height = im.height;
+  if (width + height == 0) return v3(0, 0, 0);
+  V3 u = tile_clamp(uvw);
+  float x = width * u.x;
+  float y = height * u.y;
+  int ix = (int)x;
+  int iy = (int)y;
+  float fx = x - ix;
+  float fy = y - iy;
+  if (ix < 0) ix -= (ix / width - 1) * width;
+  if (ix >= width) ix -= (ix / width) * width;
+  int ixp = ix + 1;
+  if (ixp >= width) ixp -= width;
+  if (iy < 0) iy -= (iy / height - 1) * height;
+  if (iy >= height) iy -= (iy / height) * height;
+  int iyp = iy + 1;
+  if (iyp >= height) iyp -= height;
+  const uint8_t* base = S.texels + im.offset;
+  const uint8_t* p00 = base + 3 * ((size_t)iy * width + ix);
+  const uint8_t* p10 = base + 3 * ((size_t)iy * width + ixp);
+  const uint8_t* p01 = base + 3 * ((size_t)iyp * width + ix);
+  const uint8_t* p11 = base + 3 * ((size_t)iyp * width + ixp);
+  V3 c00 = v3(p00[0] / 255.0f, p00[1] / 255.0f, p00[2] / 255.0f);
+  V3 c10 = v3(p10[0] / 255.0f, p10[1] / 255.0f, p10[2] / 255.0f);
+  V3 c01 = v3(p01[0] / 255.0f, p01[1] / 255.0f, p01[2] / 255.0f);
+  V3 c11 = v3(p11[0] / 255.0f, p11[1] / 255.0f, p11[2] / 255.0f);
+  return c00 * ((1 - fx) * (1 - fy)) + c10 * (fx * (1 - fy)) + c01 * ((1 - fx) * fy) + c11 * (fx * fy);
+}
+
+// TexturedValue<Color>::Eval.  Checker colours may be textured again (xmlload.cpp:370-374); the nesting is
+// walked iteratively: value_0 * value_1 * ... * leaf texture, each level evaluated at the uvw transformed so far.
+template <bool CNT>
+RT_DEV V3 eval_tex_color(const DScene& S, DTexColor tc, V3 uvw, Cnt<CNT>& cnt) {
+  V3 acc = v3(tc.v[0], tc.v[1], tc.v[2]);
+  int map = tc.map;
+  for (int depth = 0; depth < 8 && map >= 0; depth++) {
+    const DTexmap& tm = S.texmaps[map];
+    V3 u = xf_point(tm.itm, uvw);
+    cnt.tex();
+    if (tm.kind == 2) {
+      acc = acc * image_eval(S, S.images[tm.image], u);
+      return acc;
+    }
+    V3 t = tile_clamp(u);
+    int k = (t.x <= 0.5f) ^ (t.y <= 0.5f);
+    DTexColor c = tm.color[k];
+    acc = acc * v3(c.v[0], c.v[1], c.v[2]);
+    map = c.map;
+    uvw = u;
+  }
+  return acc;
+}
+template <bool CNT>
+RT_DEV float eval_tex_float(const DScene& S, DTexFloat tf, V3 uvw, Cnt<CNT>& cnt) {
+  if (tf.map < 0) return tf.v;
+  DTexColor tc;
+  tc.v[0] = tc.v[1] = tc.v[2] = 1.0f;
+  tc.map = tf.map;
+  return tf.v * eval_tex_color<CNT>(S, tc, uvw, cnt).x;
+}
+template <bool CNT>
+RT_DEV V3 eval_environment(const DScene& S, DTexColor tc, V3 dir, Cnt<CNT>& cnt) {  // scene.h:377-384
+  if (tc.map < 0) return v3(tc.v[0], tc.v[1], tc.v[2]);
+  float len = length(dir);
+  float z = asinf(-dir.z / len) / RT_PI_F + 0.5f;
+  float x = dir.x / (fabsf(dir.x) + fabsf(dir.y));
+  float y = dir.y / (fabsf(dir.x) + fabsf(dir.y));
+  return eval_tex_color<CNT>(S, tc, v3(0.5f + 0.5f * z * (x - y), 0.5f + 0.5f * z * (x + y), 0.0f), cnt);
+}
+
+// Color24(Color) channel and Linear2sRGB as this build defines them (see oracle.cpp)
+RT_HD uint8_t to_byte(float v) {
+  if (!(v == v)) return 0;
+  float s = v * 255.0f + 0.5f;
+  if (s <= 0.0f) return 0;
+  if (s >= 255.0f) return 255;
+  return (uint8_t)(int)s;
+}
+RT_HD float linear_to_srgb(float v) { return v < 0.0031308f ? v * 12.92f : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f; }

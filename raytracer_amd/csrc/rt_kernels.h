@@ -1,0 +1,695 @@
+// Kernels of the wavefront (queue-per-stage) integrator.
+//
+// One camera sample = one "path slot".  Stages, each a grid-stride kernel over a device-side queue whose length
+// lives in device memory (no host round trip between stages):
+//   k_raygen         RunThread's camera-ray construction            (RayTracer.cpp:138-174)
+//   k_trace_closest  Renderer::TraceRay for a ray queue             (RayTracer.cpp:373-435, objects.cpp)
+//   k_shade          SendRay's dispatch + MtlBlinn::Shade + the light loop's unshadowed BRDF terms; appends
+//                    refraction / reflection / indirect rays to the next level's queue and shadow work to the
+//                    shadow queues                                  (RayTracer.cpp:227-259, materials.cpp:222-331)
+//   k_shadow_*       PointLight/DirectLight::Illuminate's shadow rays (lights.cpp:19-72, lights.h:45)
+//   k_accumulate     per-pixel sum / sum of squares / adaptive stop (RayTracer.cpp:176-198)
+//   k_resolve        mean, sRGB, Color24                            (RayTracer.cpp:206-216)
+// The recursion L = direct + reflection*L(refl) + refraction*(1-R)*L(refr) is linear in the children, so it is
+// unrolled into per-ray weights; absorption is applied when the child's hit distance is known.
+#pragma once
+#include "rt_device.h"
+
+struct RayQ {
+  float4* q0;  // origin.xyz, weight.r
+  float4* q1;  // dir.xyz,    weight.g
+  float4* q2;  // parent absorption.rgb, weight.b
+  uint4* q3;   // path slot, pixel index, camera sample index, meta
+  float4* h0;  // hit p.xyz, z
+  float4* h1;  // hit N.xyz, instance (int bits)
+  float4* h2;  // hit uvw.xyz, flags (bit0 front, bits 8.. light+1)
+  uint32_t* count;
+  uint32_t cap;
+};
+// meta word: tree position (12 bits) | bounce << 12 (3 bits) | secondary << 15 | reshade << 16
+#define RT_META(nid, bounce, sec, resh) ((uint32_t)(nid) | ((uint32_t)(bounce) << 12) | ((uint32_t)(sec) << 15) | ((uint32_t)(resh) << 16))
+
+struct GroupQ {  // one record per (shade point, light) whose unshadowed contribution is non-zero
+  float4* g0;    // P.xyz, light index
+  float4* g1;    // weight * unshadowed BRDF term rgb, path slot
+  float4* g2;    // disc offsets rx, ry (lights.cpp:25-26), lit-sample counter, unused
+  uint32_t* count;
+  uint32_t cap;
+};
+
+struct GatherQ {  // photon-map lookups deferred to k_photon_gather (materials.cpp:315-322)
+  float4* a;      // P.xyz, path slot
+  float4* b;      // N.xyz, which map (0 global, 1 caustics)
+  float4* c;      // weight * kd / pi rgb
+  uint32_t* count;
+  uint32_t cap;
+};
+
+struct PassP {
+  // camera constants, computed on the host exactly as RunThread does (RayTracer.cpp:95-101, 15-22)
+  float X[3], Y[3], Z[3], pos[3];
+  float l, wh, ww, camW, camH, dof;
+  int32_t W, H;
+  int32_t jitter;
+  uint32_t seed_lo, seed_hi;
+  int32_t sample_base;   // camera-sample index of the first sample of this pass
+  int32_t n_samples;     // samples per pixel in this pass
+  uint32_t n_pix;        // pixels in this pass (length of `pixels`)
+  int32_t max_bounces, mc_bounces, mc_samples;
+  int32_t shadow_min, shadow_max;
+  float light_size_scale;
+  int32_t photons;
+  int32_t srgb;
+  int32_t aov_sample;    // write hit AOVs for this camera-sample index (-1 none)
+  int32_t spp_min, spp_max, adaptive;
+  float adaptive_threshold;
+};
+
+struct FrameBufs {
+  const uint32_t* pixels;  // pixel indices of this pass, ordered in 8x8 tiles
+  float4* path_rad;        // n_pix * n_samples path radiance slots
+  float* accum;            // W*H*8: sum rgb, n, sum of squares rgb, done flag
+  int32_t* hit_node;       // W*H AOVs (may be null)
+  int32_t* hit_face;
+  uint32_t* overflow;
+  DCounters* counters;
+};
+
+RT_DEV uint32_t queue_push(uint32_t* count, uint32_t cap, uint32_t* overflow) {
+  uint32_t i = rt_atomic_add_u32(count, 1u);
+  if (i >= cap) {
+    *overflow = 1u;
+    return 0xFFFFFFFFu;
+  }
+  return i;
+}
+
+RT_DEV float two_pi_times(float x) { return (float)(2.0 * RT_PI_D * (double)x); }  // `2.0f * M_PI * x` promotes to double
+
+#ifndef RT_EMU
+#define RT_STACK_DECL __shared__ uint32_t s_stack[RT_STACK * RT_BLOCK]; uint32_t* stk = s_stack + RT_LANE_IN_BLOCK; const uint32_t stride = RT_BLOCK;
+#else
+#define RT_STACK_DECL uint32_t s_stack[RT_STACK]; uint32_t* stk = s_stack; const uint32_t stride = 1;
+#endif
+
+// ------------------------------------------------------------------------------------------------ raygen
+RT_KERNEL(k_raygen, DScene S, PassP P, FrameBufs F, RayQ Q) {
+  uint32_t total = P.n_pix * (uint32_t)P.n_samples;
+  for (uint32_t idx = RT_TID; idx < total; idx += RT_NTHREADS) {
+    uint32_t j = idx % P.n_pix, k = idx / P.n_pix;
+    uint32_t pixel = F.pixels[j];
+    int x = (int)(pixel % (uint32_t)P.W), y = (int)(pixel / (uint32_t)P.W);
+    int i = P.sample_base + (int)k;
+    float hx = 0, hy = 0;
+    V3 camOff = v3(0, 0, 0);
+    if (P.jitter) {
+      uint32_t r[4];
+      philox4x32_10(pixel, 0, 0, RT_TAG_PIXEL, P.seed_lo, P.seed_hi, r);
+      float ro = u32_to_unit(r[0]), roy = u32_to_unit(r[1]);
+      hx = S.halton[RT_H2 + (i & 127)] + ro;   // RayTracer.cpp:138-144 (Y also uses randomOffset)
+      if (hx > 1.0f) hx -= 1.0f;
+      hy = S.halton[RT_H3 + (i & 127)] + ro;
+      if (hy > 1.0f) hy -= 1.0f;
+      float discX = S.halton[RT_H5 + (i & 127)] + ro;   // :152-157
+      float discY = S.halton[RT_H7 + (i & 127)] + roy;
+      if (discX > 1.0f) discX -= 1.0f;
+      if (discY > 1.0f) discY -= 1.0f;
+      float r_ = sqrtf(discX);
+      float angle = two_pi_times(discY);
+      float lensU = r_ * P.dof * cosf(angle);
+      float lensV = r_ * P.dof * sinf(angle);
+      camOff = v3(lensU, lensV, 0.0f);
+    }
+    float pixX = -(P.ww / 2.0f) + ((P.ww * ((float)x + (1.0f / 2.0f) + hx) / P.camW));   // :147
+    float pixY = (P.wh / 2.0f) - ((P.wh * ((float)y + (1.0f / 2.0f) + hy) / P.camH));    // :148
+    V3 pixelPos = v3(pixX, pixY, -P.l);
+    V3 X = v3(P.X[0], P.X[1], P.X[2]), Y = v3(P.Y[0], P.Y[1], P.Y[2]), Z = v3(P.Z[0], P.Z[1], P.Z[2]);
+    V3 worldCamera = X * camOff.x + Y * camOff.y + Z * camOff.z;      // cam2Wrld * (v, 0), :165-166
+    V3 worldPixel = X * pixelPos.x + Y * pixelPos.y + Z * pixelPos.z;
+    V3 origin = v3(P.pos[0], P.pos[1], P.pos[2]) + worldCamera;
+    V3 dir = worldPixel - worldCamera;
+    Q.q0[idx] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+    Q.q1[idx] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+    Q.q2[idx] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    uint4 m;
+    m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
+    Q.q3[idx] = m;
+    F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (RT_TID == 0) *Q.count = total;
+}
+
+// ------------------------------------------------------------------------------------------------ trace
+template <bool CNT>
+RT_DEV void trace_closest_body(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, int level, uint32_t* stk, uint32_t stride) {
+  uint32_t n = *Q.count;
+  if (n > Q.cap) n = Q.cap;
+  Cnt<CNT> cnt;
+  uint32_t traced = 0;
+  for (uint32_t idx = RT_TID; idx < n; idx += RT_NTHREADS) {
+    uint4 m = Q.q3[idx];
+    if (m.w & (1u << 16)) continue;  // re-shade entry: hit record was written by k_shade (lights.cpp:172-183)
+    float4 a = Q.q0[idx], b = Q.q1[idx];
+    Hit h;
+    traced++;
+    // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
+    scene_closest<CNT>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), level == 0 ? 1 : 3, h, stk, stride, cnt);
+    uint32_t flags = (h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8);
+    Q.h0[idx] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+    Q.h1[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
+    Q.h2[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float(flags));
+    if (level == 0 && F.hit_node && (int)m.z == P.aov_sample) {
+      F.hit_node[m.y] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
+      F.hit_face[m.y] = h.light >= 0 ? -1 : h.face;
+    }
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    cnt.flush_closest(F.counters);
+    if (traced) rt_atomic_add_u64(level == 0 ? &F.counters->rays_primary : &F.counters->rays_secondary, traced);
+  }
+}
+template <bool CNT>
+RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, int level) {
+  RT_STACK_DECL
+  trace_closest_body<CNT>(S, P, F, Q, level, stk, stride);
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+struct ShadePt {
+  V3 P, N, V, uvw;
+  bool front;
+  uint32_t pixel, nid;
+  int sample;
+};
+
+// glossy half vector, materials.cpp:35-49 / 79-94
+RT_DEV V3 gloss_half(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta, bool renorm) {
+  int gi = sp.sample < S.n_gloss ? sp.sample : S.n_gloss - 1;
+  float phi = two_pi_times(fmodf(S.halton[RT_HGLOSS + gi] + oPhi, 1.0f));
+  float cosTheta = powf(fmodf(S.halton[RT_HGLOSS + S.n_gloss + gi] + oTheta, 1.0f), 1.0f / (gloss + 1.0f));
+  float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
+  float x = sinTheta * cosf(phi);
+  float y = sinTheta * sinf(phi);
+  float z = cosTheta;
+  V3 t, b;
+  orthonormals(sp.N, t, b);
+  V3 H = (x * t) + (y * b) + (z * sp.N);
+  if (renorm) H = normalized(H);
+  return H;
+}
+RT_DEV V3 reflect_dir(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta) {  // materials.cpp:30-59
+  V3 H = gloss_half(S, sp, gloss, oPhi, oTheta, false);
+  float d = dot(H, sp.V);
+  V3 dir = (2 * d) * H - sp.V;
+  return normalized(dir);
+}
+// RefractRay, materials.cpp:70-133.  r0 = block-0 draws, r1 = block-1 draws (used on total internal reflection).
+RT_DEV void refract_ray(const DScene& S, const ShadePt& sp, float ior, float gloss, const float* r0, const float* r1, V3& o, V3& d) {
+  const float eps = 1e-4f;
+  V3 view = sp.V;
+  V3 H = gloss_half(S, sp, gloss, r0[0], r0[1], true);
+  if (sp.front) {
+    float eta = 1 / ior;
+    float etaSq = eta * eta;
+    float NdotV = dot(view, H);
+    float cosThetaT = sqrtf(1 - etaSq * (1 - NdotV * NdotV));
+    V3 dir = -eta * view - (cosThetaT - eta * NdotV) * H;
+    d = normalized(dir);
+    float sign = dot(d, sp.N) > 0.0f ? 1.0f : -1.0f;
+    o = sp.P + sp.N * (eps * sign);
+  } else {
+    float eta = ior;
+    V3 Hb = -H;
+    V3 negN = -sp.N;
+    float NdotV = dot(view, Hb);
+    float etaSq = eta * eta;
+    float cosThetaSquared = (float)(1.0 - (double)(etaSq * (1 - NdotV * NdotV)));
+    if (cosThetaSquared < 0.0f) {
+      o = sp.P;
+      d = reflect_dir(S, sp, gloss, r1[0], r1[1]);
+      return;
+    }
+    float cosThetaT = sqrtf(cosThetaSquared);
+    V3 dir = -eta * view - (cosThetaT - eta * NdotV) * Hb;
+    d = normalized(dir);
+    float sign = dot(d, negN) > 0.0f ? 1.0f : -1.0f;
+    o = sp.P + negN * (eps * sign);
+  }
+}
+
+RT_DEV void shade_draws(const PassP& P, const ShadePt& sp, uint32_t block, float out[4]) {
+  uint32_t r[4];
+  philox4x32_10(sp.pixel, sp.nid, block, RT_TAG_SHADE, P.seed_lo, P.seed_hi, r);
+  out[0] = u32_to_unit(r[0]); out[1] = u32_to_unit(r[1]); out[2] = u32_to_unit(r[2]); out[3] = u32_to_unit(r[3]);
+}
+
+RT_DEV void add_radiance(const FrameBufs& F, uint32_t slot, V3 c) {
+  float* p = (float*)&F.path_rad[slot];
+  if (c.x != 0.0f) rt_atomic_add_f32(p + 0, c.x);
+  if (c.y != 0.0f) rt_atomic_add_f32(p + 1, c.y);
+  if (c.z != 0.0f) rt_atomic_add_f32(p + 2, c.z);
+}
+
+RT_DEV V3 absorb(V3 c, V3 ab, float dist) {  // materials.cpp:255-259
+  if (dist > 0.0f && (ab.x > 0.0f || ab.y > 0.0f || ab.z > 0.0f)) {
+    c.x *= expf(-ab.x * dist);
+    c.y *= expf(-ab.y * dist);
+    c.z *= expf(-ab.z * dist);
+  }
+  return c;
+}
+
+template <bool CNT>
+RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
+  uint32_t n = *Q.count;
+  if (n > Q.cap) n = Q.cap;
+  Cnt<CNT> cnt;
+  uint32_t n_shades = 0;
+  for (uint32_t idx = RT_TID; idx < n; idx += RT_NTHREADS) {
+    float4 q0 = Q.q0[idx], q1 = Q.q1[idx], q2 = Q.q2[idx];
+    uint4 m = Q.q3[idx];
+    float4 h0 = Q.h0[idx], h1 = Q.h1[idx], h2 = Q.h2[idx];
+    V3 w = v3(q0.w, q1.w, q2.w);
+    V3 pabs = v3(q2.x, q2.y, q2.z);
+    V3 rdir = v3(q1.x, q1.y, q1.z);
+    uint32_t slot = m.x, pixel = m.y;
+    uint32_t nid = m.w & 0xFFFu, bounce = (m.w >> 12) & 7u;
+    bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
+    int inst = (int)__float_as_uint(h1.w);
+    uint32_t flags = __float_as_uint(h2.w);
+    int light = (int)((flags >> 8) & 0xFFFFu) - 1;
+    bool front = flags & 1u;
+    float z = h0.w;
+
+    if (inst < 0 && light < 0) {  // miss
+      if (bounce == 0) {          // RayTracer.cpp:253-258
+        float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
+        float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
+        add_radiance(F, slot, w * eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt));
+      } else {                    // lights.cpp:204-208, dist = BIGFLOAT
+        V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
+        add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
+      }
+      continue;
+    }
+    if (light >= 0) {
+      if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
+        const DLight& L = S.lights[light];
+        V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
+        add_radiance(F, slot, w * c);
+      } else {                    // lights.cpp:199-202
+        add_radiance(F, slot, w * absorb(v3(1, 1, 1), pabs, z));
+      }
+      continue;
+    }
+
+    // SamplerInfo::SetHit, renderer.h:142-150
+    ShadePt sp;
+    float zs = z * length(rdir);
+    sp.N = normalized(v3(h1.x, h1.y, h1.z));
+    V3 nd = normalized(rdir);
+    sp.V = -nd;
+    sp.P = v3(h0.x, h0.y, h0.z);
+    sp.uvw = v3(h2.x, h2.y, h2.z);
+    sp.front = front;
+    sp.pixel = pixel;
+    sp.nid = nid;
+    sp.sample = (int)m.z;
+    if (bounce > 0) {  // lights.cpp:194 and materials.cpp:255-259 / 277-281, applied to this subtree's weight
+      float dist = reshade ? 0.0f : (front ? zs : 0.0f);
+      w = absorb(w, pabs, dist);
+    }
+    n_shades++;
+    const DInstance& I = S.inst[inst];
+    const DMaterial& M = S.materials[I.mtl];
+    if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
+      add_radiance(F, slot, w);
+      continue;
+    }
+    // materials.cpp:231-236
+    V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
+    V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
+    V3 kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
+    V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
+    float alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
+    V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
+    float diffScalar = (float)(1 / RT_PI_D);
+    float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
+    V3 cKd = kd * diffScalar;
+    V3 cKs = ks * specScalar;
+    V3 fullReflection = reflection;
+    V3 mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
+    bool can_bounce = (int)bounce < P.max_bounces;
+    float r0[4], r1[4];
+    bool have_r0 = false, have_r1 = false;
+
+    if (M.ior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
+      float iorRatio = (1.0f - M.ior) / (1.0f + M.ior);
+      V3 fresnel = refraction * (iorRatio * iorRatio);
+      fullReflection = fullReflection + fresnel;
+      V3 wc = w * (refraction * (v3(1, 1, 1) - fullReflection));
+      if (nonzero(wc)) {
+        shade_draws(P, sp, 0, r0); have_r0 = true;
+        shade_draws(P, sp, 1, r1); have_r1 = true;
+        V3 o, d;
+        refract_ray(S, sp, M.ior, M.glossiness.v, r0, r1, o, d);
+        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
+        if (ci != 0xFFFFFFFFu) {
+          QN.q0[ci] = make_float4(o.x, o.y, o.z, wc.x);
+          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
+          QN.q2[ci] = make_float4(mabs.x, mabs.y, mabs.z, wc.z);
+          uint4 cm;
+          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
+          QN.q3[ci] = cm;
+        }
+      }
+    }
+    if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
+      V3 wc = w * reflection;
+      if (nonzero(wc)) {
+        if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
+        V3 d = reflect_dir(S, sp, M.glossiness.v, r0[2], r0[3]);
+        bool below = dot(d, sp.N) < 0;  // lights.cpp:174: re-shade the same point with the new view direction
+        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
+        if (ci != 0xFFFFFFFFu) {
+          QN.q0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, wc.x);
+          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
+          QN.q2[ci] = make_float4(mabs.x, mabs.y, mabs.z, wc.z);
+          uint4 cm;
+          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 2, bounce + 1, 1, below ? 1 : 0);
+          QN.q3[ci] = cm;
+          if (below) {
+            QN.h0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, zs);
+            QN.h1[ci] = make_float4(sp.N.x, sp.N.y, sp.N.z, h1.w);
+            QN.h2[ci] = h2;
+          }
+        }
+      }
+    }
+
+    // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
+    for (int li = 0; li < S.n_lights; li++) {
+      const DLight& L = S.lights[li];
+      if (L.kind == 1) continue;  // ambient is accumulated and never added
+      V3 lightDir, inten = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
+      bool soft = false;
+      if (L.kind == 2) {  // lights.h:45
+        lightDir = -v3(L.direction[0], L.direction[1], L.direction[2]);
+      } else {            // lights.cpp:62-71
+        V3 dl = v3(L.position[0], L.position[1], L.position[2]) - sp.P;
+        float dist = length(dl);
+        lightDir = normalized(dl);
+        if (L.attenuation != 0.0f) inten = inten / (dist * dist);
+        soft = (L.size * P.light_size_scale) != 0.0f;
+      }
+      V3 h = normalized(lightDir + sp.V);
+      float cosphi = fmaxf(dot(sp.N, h), 0.0f);
+      float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
+      V3 contrib = w * (inten * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
+      if (!nonzero(contrib)) continue;
+      GroupQ& G = soft ? GS : GH;
+      uint32_t gi = queue_push(G.count, G.cap, F.overflow);
+      if (gi == 0xFFFFFFFFu) continue;
+      float rx = 0, ry = 0;
+      if (soft) {
+        float rl[4];
+        shade_draws(P, sp, 2 + (uint32_t)li, rl);
+        rx = rl[0]; ry = rl[1];
+      }
+      G.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
+      G.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+      G.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), 0.0f);
+    }
+
+    V3 local = emission;
+    if (P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
+      V3 wc = w * kd;
+      if (nonzero(wc)) {
+        if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
+        int hi = (sp.sample * P.mc_samples) % 1000;
+        float u1 = fmodf(S.halton[RT_HPHI + hi] + r1[2], 1.0f);
+        float u2 = fmodf(S.halton[RT_HTHETA + hi] + r1[3], 1.0f);
+        float r = sqrtf(u1);
+        float phi = two_pi_times(u2);
+        float x = r * cosf(phi), y = r * sinf(phi), zz = sqrtf(1.0f - u1);
+        V3 t, b;
+        orthonormals(sp.N, t, b);
+        V3 d = normalized((x * t) + (y * b) + (zz * sp.N));
+        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
+        if (ci != 0xFFFFFFFFu) {
+          QN.q0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, wc.x);
+          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
+          QN.q2[ci] = make_float4(0.0f, 0.0f, 0.0f, wc.z);  // `dist` is unused by the sampler: no absorption
+          uint4 cm;
+          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
+          QN.q3[ci] = cm;
+        }
+      }
+    } else if (P.photons) {  // materials.cpp:315-322
+      V3 wk = w * ((float)(1.0f / RT_PI_D) * kd);
+      if (nonzero(wk)) {
+        uint32_t gi = queue_push(GQ.count, GQ.cap, F.overflow);
+        if (gi != 0xFFFFFFFFu) {
+          GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));
+          GQ.b[gi] = make_float4(sp.N.x, sp.N.y, sp.N.z, __uint_as_float(secondary ? 1u : 0u));
+          GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
+        }
+      }
+    }
+    add_radiance(F, slot, w * local);
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ shadows
+// Hard shadows: one ray per group (DirectLight, and PointLight of size 0 where the reference's 16..128 rays are
+// identical).
+template <bool CNT>
+RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G) {
+  RT_STACK_DECL
+  uint32_t n = *G.count;
+  if (n > G.cap) n = G.cap;
+  Cnt<CNT> cnt;
+  uint32_t rays = 0;
+  for (uint32_t g = RT_TID; g < n; g += RT_NTHREADS) {
+    float4 g0 = G.g0[g], g1 = G.g1[g];
+    V3 Pp = v3(g0.x, g0.y, g0.z);
+    const DLight& L = S.lights[__float_as_uint(g0.w)];
+    V3 d;
+    float tmax;
+    if (L.kind == 2) {
+      d = -v3(L.direction[0], L.direction[1], L.direction[2]);
+      tmax = RT_BIG;
+    } else {
+      V3 toLight = v3(L.position[0], L.position[1], L.position[2]) - Pp;
+      tmax = length(toLight);
+      d = toLight / tmax;
+    }
+    rays++;
+    if (!scene_any<CNT>(S, Pp, d, tmax, stk, stride, cnt)) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
+  }
+}
+
+// Soft shadows, PointLight::Illuminate (lights.cpp:34-60): sample j of group g.
+template <bool CNT>
+RT_DEV bool soft_sample_lit(const DScene& S, const PassP& P, float4 g0, float4 g2, uint32_t j, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  V3 Pp = v3(g0.x, g0.y, g0.z);
+  const DLight& L = S.lights[__float_as_uint(g0.w)];
+  V3 position = v3(L.position[0], L.position[1], L.position[2]);
+  float size = L.size * P.light_size_scale;
+  V3 toSP = normalized(Pp - position);
+  V3 tangent, bitangent;
+  orthonormals(toSP, tangent, bitangent);
+  const float twoPi = (float)(2 * RT_PI_D);
+  float discX = S.halton[RT_H2 + (j & 127)] + g2.x;
+  float discY = S.halton[RT_H3 + (j & 127)] + g2.y;
+  discX -= (discX > 1.0f) ? 1.0f : 0.0f;
+  discY -= (discY > 1.0f) ? 1.0f : 0.0f;
+  float r = sqrtf(discX) * size;
+  float angle = twoPi * discY;
+  float offsetU = r * cosf(angle);
+  float offsetV = r * sinf(angle);
+  V3 lsp = position + (tangent * offsetU) + (bitangent * offsetV);
+  V3 toLight = lsp - Pp;
+  float dist = length(toLight);
+  V3 d = toLight / dist;
+  return !scene_any<CNT>(S, Pp, d, dist, stk, stride, cnt);
+}
+
+// phase 1: the first shadow_min samples of every group, one lane per (group, sample)
+template <bool CNT>
+RT_KERNEL(k_shadow_soft1, DScene S, PassP P, FrameBufs F, GroupQ G) {
+  RT_STACK_DECL
+  uint32_t n = *G.count;
+  if (n > G.cap) n = G.cap;
+  uint32_t n1 = (uint32_t)P.shadow_min;
+  unsigned long long total = (unsigned long long)n * n1;
+  Cnt<CNT> cnt;
+  uint32_t rays = 0;
+  for (unsigned long long r = RT_TID; r < total; r += RT_NTHREADS) {
+    uint32_t g = (uint32_t)(r / n1), j = (uint32_t)(r % n1);
+    rays++;
+    if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
+  }
+}
+// early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues
+RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, uint32_t* list2, uint32_t* n2) {
+  uint32_t n = *G.count;
+  if (n > G.cap) n = G.cap;
+  for (uint32_t g = RT_TID; g < n; g += RT_NTHREADS) {
+    uint32_t lit = __float_as_uint(G.g2[g].z);
+    if (lit == (uint32_t)P.shadow_min || P.shadow_max <= P.shadow_min) {
+      float4 g1 = G.g1[g];
+      float vis = (float)lit / (float)P.shadow_min;
+      add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * vis);
+    } else {
+      list2[rt_atomic_add_u32(n2, 1u)] = g;
+    }
+  }
+}
+// phase 2: samples shadow_min .. shadow_max-1 of the groups that were not fully lit
+template <bool CNT>
+RT_KERNEL(k_shadow_soft2, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
+  RT_STACK_DECL
+  uint32_t n = *n2;
+  uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
+  unsigned long long total = (unsigned long long)n * nr;
+  Cnt<CNT> cnt;
+  uint32_t rays = 0;
+  for (unsigned long long r = RT_TID; r < total; r += RT_NTHREADS) {
+    uint32_t g = list2[(uint32_t)(r / nr)], j = (uint32_t)P.shadow_min + (uint32_t)(r % nr);
+    rays++;
+    if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
+  }
+}
+RT_KERNEL(k_shadow_soft_final, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
+  uint32_t n = *n2;
+  for (uint32_t e = RT_TID; e < n; e += RT_NTHREADS) {
+    uint32_t g = list2[e];
+    float4 g1 = G.g1[g];
+    float vis = (float)__float_as_uint(G.g2[g].z) / (float)P.shadow_max;  // summedLight / numSamples, lights.cpp:66
+    add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * vis);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate / resolve
+RT_HD float t_value(int i) {  // raytracer.h:52-58, index clamped to the table
+  const float T[71] = {0,      12.706f, 4.303f, 3.182f, 2.776f, 2.571f, 2.447f, 2.365f, 2.306f, 2.262f, 2.228f, 2.201f,
+                       2.179f, 2.160f,  2.145f, 2.131f, 2.120f, 2.110f, 2.101f, 2.093f, 2.086f, 2.080f, 2.074f, 2.069f,
+                       2.064f, 2.060f,  2.056f, 2.052f, 2.048f, 2.045f, 2.042f, 2.040f, 2.037f, 2.035f, 2.032f, 2.030f,
+                       2.028f, 2.026f,  2.024f, 2.023f, 2.021f, 2.020f, 2.018f, 2.017f, 2.015f, 2.014f, 2.013f, 2.012f,
+                       2.011f, 2.010f,  2.009f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f, 2.000f,
+                       2.000f, 1.994f,  1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f, 1.994f};
+  return T[i > 70 ? 70 : i];
+}
+
+// RayTracer.cpp:176-198 per pixel, samples in index order; accum = sum rgb, n, sum of squares rgb, done flag
+RT_KERNEL(k_accumulate, PassP P, FrameBufs F) {
+  for (uint32_t j = RT_TID; j < P.n_pix; j += RT_NTHREADS) {
+    uint32_t pixel = F.pixels[j];
+    float* a = F.accum + 8 * (size_t)pixel;
+    float sr = a[0], sg = a[1], sb = a[2], n = a[3], qr = a[4], qg = a[5], qb = a[6], done = a[7];
+    for (int k = 0; k < P.n_samples && done == 0.0f; k++) {
+      float4 c = F.path_rad[(size_t)k * P.n_pix + j];
+      sr += c.x; sg += c.y; sb += c.z;
+      qr += c.x * c.x; qg += c.y * c.y; qb += c.z * c.z;
+      n += 1.0f;
+      if (P.adaptive) {
+        int i = P.sample_base + k;
+        if (i >= P.spp_min) {
+          float nn = (float)(i + 1);
+          float vr = (qr - (sr * sr) / nn) / (nn - 1.0f);
+          float vg = (qg - (sg * sg) / nn) / (nn - 1.0f);
+          float vb = (qb - (sb * sb) / nn) / (nn - 1.0f);
+          vr = fmaxf(vr, 0.0f); vg = fmaxf(vg, 0.0f); vb = fmaxf(vb, 0.0f);
+          float t = t_value((int)nn - 1);
+          float sn = sqrtf(nn);
+          float pr = t * (sqrtf(vr) / sn), pg = t * (sqrtf(vg) / sn), pb = t * (sqrtf(vb) / sn);
+          if (pr <= P.adaptive_threshold && pg <= P.adaptive_threshold && pb <= P.adaptive_threshold) done = 1.0f;
+        }
+        if (i + 1 >= P.spp_max) done = 1.0f;  // fall-through: totalSamples = maxSamples
+      }
+    }
+    a[0] = sr; a[1] = sg; a[2] = sb; a[3] = n; a[4] = qr; a[5] = qg; a[6] = qb; a[7] = done;
+  }
+}
+
+// pixels still sampling after an adaptive pass
+RT_KERNEL(k_compact_active, PassP P, FrameBufs F, uint32_t* next_pixels, uint32_t* next_count) {
+  for (uint32_t j = RT_TID; j < P.n_pix; j += RT_NTHREADS) {
+    uint32_t pixel = F.pixels[j];
+    if (F.accum[8 * (size_t)pixel + 7] == 0.0f) next_pixels[rt_atomic_add_u32(next_count, 1u)] = pixel;
+  }
+}
+
+// RayTracer.cpp:206-216
+RT_KERNEL(k_resolve, int W, int H, int srgb, const float* accum, uint8_t* rgb8, float* radiance, int32_t* sample_count) {
+  uint32_t total = (uint32_t)W * (uint32_t)H;
+  for (uint32_t p = RT_TID; p < total; p += RT_NTHREADS) {
+    const float* a = accum + 8 * (size_t)p;
+    float n = a[3];
+    float r = a[0] / n, g = a[1] / n, b = a[2] / n;
+    if (n == 0.0f) { r = g = b = 0.0f; }  // pixel not covered by this call's tiles
+    if (radiance) {
+      radiance[4 * (size_t)p + 0] = r; radiance[4 * (size_t)p + 1] = g; radiance[4 * (size_t)p + 2] = b;
+      radiance[4 * (size_t)p + 3] = n;
+    }
+    if (srgb) { r = linear_to_srgb(r); g = linear_to_srgb(g); b = linear_to_srgb(b); }
+    if (rgb8) {
+      rgb8[3 * (size_t)p + 0] = to_byte(r); rgb8[3 * (size_t)p + 1] = to_byte(g); rgb8[3 * (size_t)p + 2] = to_byte(b);
+    }
+    if (sample_count) sample_count[p] = (int32_t)n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ batched trace API
+struct HitOut {  // rt_hit
+  float p[3];
+  float z;
+  float N[3];
+  float uvw[3];
+  int32_t node, face, light, front;
+};
+RT_KERNEL(k_api_closest, DScene S, const float* rays, uint32_t n, int hitSide, HitOut* out) {
+  RT_STACK_DECL
+  Cnt<false> cnt;
+  for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) {
+    const float* r = rays + 6 * (size_t)i;
+    Hit h;
+    bool ok = scene_closest<false>(S, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), hitSide, h, stk, stride, cnt);
+    HitOut o;
+    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+    o.z = ok ? h.z : RT_BIG;
+    o.N[0] = h.N.x; o.N[1] = h.N.y; o.N[2] = h.N.z;
+    o.uvw[0] = h.uvw.x; o.uvw[1] = h.uvw.y; o.uvw[2] = h.uvw.z;
+    o.node = (ok && h.inst >= 0) ? S.inst[h.inst].node : -1;
+    o.face = (ok && h.light < 0) ? h.face : -1;
+    o.light = ok ? h.light : -1;
+    o.front = h.front ? 1 : 0;
+    out[i] = o;
+  }
+}
+RT_KERNEL(k_api_any, DScene S, const float* rays, const float* tmax, uint32_t n, uint8_t* out) {
+  RT_STACK_DECL
+  Cnt<false> cnt;
+  for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) {
+    const float* r = rays + 6 * (size_t)i;
+    out[i] = scene_any<false>(S, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), tmax ? tmax[i] : RT_BIG, stk, stride, cnt) ? 1 : 0;
+  }
+}

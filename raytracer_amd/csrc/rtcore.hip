@@ -1,0 +1,1123 @@
+// rtcore — C-ABI implementation and host orchestration of the MI355X renderer core (include/rtcore.h).
+//
+// Built by hipcc for gfx950 into raytracer_amd/lib/librtcore.so.  (With -DRT_EMU and g++ the same file builds the
+// single-threaded host emulation used by CPU-side unit tests only; see rt_platform.h.)
+#include "rt_kernels.h"
+#include "rt_photon.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rtcore.h"
+
+// ------------------------------------------------------------------------------------------------ helpers
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+      return RT_ERR_DEVICE;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+#ifndef RT_EMU
+#define LAUNCH(kern, n_items, ...)                                                               \
+  do {                                                                                           \
+    unsigned long long ni_ = (unsigned long long)(n_items);                                      \
+    unsigned long long nb_ = (ni_ + RT_BLOCK - 1) / RT_BLOCK;                                    \
+    if (nb_ < 1) nb_ = 1;                                                                        \
+    if (nb_ > (unsigned long long)ctx->max_blocks) nb_ = ctx->max_blocks;                        \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_BLOCK), 0, ctx->stream, __VA_ARGS__);  \
+  } while (0)
+#else
+#define LAUNCH(kern, n_items, ...) kern(__VA_ARGS__)
+#endif
+
+namespace {
+
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+template <class T>
+T* dptr(const DevMem& m) { return (T*)m.p; }
+
+}  // namespace
+
+struct rt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int max_blocks = 2048;
+  bool has_scene = false;
+
+  // committed scene (device)
+  std::vector<DevMem> scene_mem;
+  DScene ds;
+  rt_camera camera;
+  int n_nodes = 0, n_hard_lights = 0, n_soft_capable = 0, n_gloss = 0;
+  std::vector<rt_light> lights;
+  std::vector<DInstance> h_inst;
+  std::vector<rt_material> h_materials;
+
+  // frame resources
+  std::vector<DevMem> frame_mem;
+  size_t frame_key[8] = {0};
+  RayQ Q[2];
+  GroupQ GH, GS;
+  GatherQ GQ;
+  uint32_t* d_list2 = nullptr;
+  uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
+  float4* d_path_rad = nullptr;
+  uint32_t* d_pixels = nullptr;
+  uint32_t* d_pixels2 = nullptr;
+  int32_t* d_hit_node = nullptr;
+  int32_t* d_hit_face = nullptr;
+  DCounters* d_counters = nullptr;
+  uint32_t path_budget = 0;
+  std::vector<uint32_t> h_pixels;
+  size_t pixel_key[6] = {0};
+
+  // photon maps
+  PhotonState photons;
+
+  bool counters_on = false, profile_on = false;
+  uint64_t host_paths = 0;
+  rt_profile prof;
+  struct Ev { hipEvent_t a, b; int kind; uint64_t items_slot; };
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<Ev> ev_used;
+
+  // async render
+  std::thread worker;
+  std::atomic<long long> pixels_done{0};
+  std::atomic<int> finished{1};
+  int async_status = RT_OK;
+};
+
+namespace {
+
+int alloc_dev(rt_context* ctx, std::vector<DevMem>& pool, size_t bytes, void** out) {
+  DevMem m;
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(hipMalloc(&m.p, bytes));
+  m.bytes = bytes;
+  pool.push_back(m);
+  *out = m.p;
+  return RT_OK;
+}
+template <class T>
+int upload(rt_context* ctx, std::vector<DevMem>& pool, const std::vector<T>& v, const T** out) {
+  void* p;
+  int rc = alloc_dev(ctx, pool, v.size() * sizeof(T), &p);
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return RT_OK;
+}
+void free_pool(std::vector<DevMem>& pool) {
+  for (auto& m : pool) m.release();
+  pool.clear();
+}
+
+float host_u2f(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+float halton_ref(int index, int base) {  // rng.h:103-112
+  float r = 0;
+  float f = 1.0f / (float)base;
+  for (int i = index; i > 0; i /= base) {
+    r += f * (i % base);
+    f /= (float)base;
+  }
+  return r;
+}
+
+DTexColor conv_tc(const rt_tex_color& t) {
+  DTexColor d;
+  d.v[0] = t.value[0]; d.v[1] = t.value[1]; d.v[2] = t.value[2];
+  d.map = t.map;
+  return d;
+}
+DMaterial conv_mtl(const rt_material& m) {
+  DMaterial d;
+  d.kind = m.kind;
+  d.diffuse = conv_tc(m.diffuse); d.specular = conv_tc(m.specular); d.emission = conv_tc(m.emission);
+  d.reflection = conv_tc(m.reflection); d.refraction = conv_tc(m.refraction);
+  d.glossiness.v = m.glossiness.value; d.glossiness.map = m.glossiness.map;
+  d.absorption[0] = m.absorption[0]; d.absorption[1] = m.absorption[1]; d.absorption[2] = m.absorption[2];
+  d.ior = m.ior;
+  return d;
+}
+rt_material default_material() {  // MtlBasePhongBlinn defaults (materials.h:53-60), SURVEY Q16
+  rt_material m;
+  std::memset(&m, 0, sizeof m);
+  m.kind = RT_MTL_BLINN;
+  m.diffuse = {{0.5f, 0.5f, 0.5f}, -1};
+  m.specular = {{0.7f, 0.7f, 0.7f}, -1};
+  m.glossiness = {20.0f, -1};
+  m.emission = {{0, 0, 0}, -1};
+  m.reflection = {{0, 0, 0}, -1};
+  m.refraction = {{0, 0, 0}, -1};
+  m.ior = 1.5f;
+  return m;
+}
+
+// Converts one rt_mesh BVH (32-byte nodes, leaf element lists) to the device layout: 64-byte internal nodes that
+// hold both child boxes (one fetch per visit) and 48-byte triangle slots (v0, e1, e2 + tie key + face id) stored
+// in depth-first leaf order.
+struct MeshConv {
+  const rt_mesh& m;
+  std::vector<float4>& nodes;
+  std::vector<float4>& tris;
+  size_t node_base, tri_base;
+  uint32_t n_internal = 0, n_slots = 0, n_leaves = 0;
+  size_t visited = 0;
+  int max_depth = 0;
+  std::string err;
+  MeshConv(const rt_mesh& mm, std::vector<float4>& n, std::vector<float4>& t) : m(mm), nodes(n), tris(t) {
+    node_base = n.size();
+    tri_base = t.size();
+  }
+  bool convert(uint32_t idx, int depth, uint32_t& ref) {
+    if (idx >= m.n_bvh_nodes) { err = "BVH child index out of range"; return false; }
+    if (++visited > m.n_bvh_nodes) { err = "BVH is not a tree"; return false; }
+    if (depth > RT_STACK) { err = "BVH deeper than 32 levels"; return false; }
+    max_depth = std::max(max_depth, depth);
+    const rt_bvh_node& n = m.bvh[idx];
+    if (n.b & RT_BVH_LEAF_BIT) {
+      uint32_t count = n.b & ~RT_BVH_LEAF_BIT;
+      if (count > 7) { err = "BVH leaf with more than 7 elements"; return false; }
+      if ((size_t)n.a + count > m.n_bvh_elements) { err = "BVH leaf elements out of range"; return false; }
+      uint32_t first = n_slots;
+      for (uint32_t s = 0; s < count; s++) {
+        uint32_t face = m.bvh_elements[n.a + s];
+        if (face >= m.n_faces) { err = "BVH element is not a face"; return false; }
+        const uint32_t* f = &m.pos_idx[3 * (size_t)face];
+        const float* v0 = &m.positions[3 * (size_t)f[0]];
+        const float* v1 = &m.positions[3 * (size_t)f[1]];
+        const float* v2 = &m.positions[3 * (size_t)f[2]];
+        uint32_t key = n_leaves * 8u + (7u - s);
+        float4 a = make_float4(v0[0], v0[1], v0[2], host_u2f(key));
+        float4 b = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], host_u2f(face));  // edge1, objects.cpp:203
+        float4 c = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.0f);                     // edge2, objects.cpp:204
+        tris.push_back(a); tris.push_back(b); tris.push_back(c);
+        n_slots++;
+      }
+      n_leaves++;
+      if (first >= (1u << 28)) { err = "mesh too large"; return false; }
+      ref = RT_LEAF | (first << 3) | count;
+      return true;
+    }
+    uint32_t me = n_internal++;
+    size_t at = node_base + 4 * (size_t)me;
+    nodes.resize(std::max(nodes.size(), at + 4));
+    if (n.a >= m.n_bvh_nodes || n.b >= m.n_bvh_nodes) { err = "BVH child index out of range"; return false; }
+    const rt_bvh_node& l = m.bvh[n.a];
+    const rt_bvh_node& r = m.bvh[n.b];
+    uint32_t lref, rref;
+    if (!convert(n.a, depth + 1, lref)) return false;
+    if (!convert(n.b, depth + 1, rref)) return false;
+    nodes[at + 0] = make_float4(l.bmin[0], l.bmin[1], l.bmin[2], l.bmax[0]);
+    nodes[at + 1] = make_float4(l.bmax[1], l.bmax[2], r.bmin[0], r.bmin[1]);
+    nodes[at + 2] = make_float4(r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]);
+    nodes[at + 3] = make_float4(host_u2f(lref), host_u2f(rref), 0.0f, 0.0f);
+    ref = me;
+    return true;
+  }
+};
+
+int fail(rt_context* ctx, int code, const std::string& msg) {
+  ctx->err = msg;
+  return code;
+}
+
+// ---- photon pass entry points (filled in by the photon-map milestone)
+int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params& RP) {
+  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore (set params.photons = 0)");
+}
+int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
+  *n = 0;
+  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore");
+}
+int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius,
+                      float ellipticity, int k, float* irradiance) {
+  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore");
+}
+void photon_gather_queue(PhotonState& ps, hipStream_t stream, int max_blocks, const GatherQ& GQ, const FrameBufs& F,
+                         const rt_render_params& RP, uint64_t upper) {}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+void rt_render_params_default(rt_render_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  p->sampler = RT_SAMPLER_PHILOX;
+  p->seed_lo = 1;
+  p->spp_min = 32;   // raytracer.h:21
+  p->spp_max = 128;  // raytracer.h:20
+  p->adaptive_threshold = 0.01f;  // RayTracer.cpp:191
+  p->pixel_jitter = 1;
+  p->max_bounces = 3;  // raytracer.h:17
+  p->mc_bounces = 0;   // the indirect-diffuse sampler is commented out in the reference (materials.cpp:309-314)
+  p->mc_samples = 1;   // renderer.h:172
+  p->shadow_min = 16;  // renderer.h:174
+  p->shadow_max = 128; // renderer.h:173
+  p->light_size_scale = 1.0f;
+  p->dedup_hard_shadows = 1;
+  p->photons = 1;
+  p->n_photons = 100000;  // raytracer.h:23
+  p->photon_radius = 3.0f;  // materials.cpp:316,320
+  p->photon_k = 128;
+  p->ellipticity_global = 1.0f;
+  p->ellipticity_caustic = 0.25f;
+  p->skip_zero_weight = 1;
+}
+
+int rt_context_create(int device_id, rt_context** out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_ERR_DEVICE;
+  if (device_id < 0 || device_id >= n) return RT_ERR_INVALID;
+  rt_context* ctx = new rt_context;
+  ctx->device = device_id;
+  std::memset(&ctx->prof, 0, sizeof ctx->prof);
+  std::memset(&ctx->ds, 0, sizeof ctx->ds);
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+    delete ctx;
+    return RT_ERR_DEVICE;
+  }
+#ifndef RT_EMU
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+    ctx->max_blocks = prop.multiProcessorCount * 4;  // 4 x 256-thread blocks per CU: 32 KB LDS stack each
+#endif
+  void* p = nullptr;
+  if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
+  ctx->d_counters = (DCounters*)p;
+  (void)hipMemset(p, 0, sizeof(DCounters));
+  *out = ctx;
+  return RT_OK;
+}
+
+void rt_context_destroy(rt_context* ctx) {
+  if (!ctx) return;
+  if (ctx->worker.joinable()) ctx->worker.join();
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_pool(ctx->scene_mem);
+  free_pool(ctx->frame_mem);
+  photon_state_free(ctx->photons);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!sc || !sc->nodes || sc->n_nodes == 0) return fail(ctx, RT_ERR_INVALID, "scene has no nodes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->worker.joinable()) ctx->worker.join();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  free_pool(ctx->scene_mem);
+  ctx->has_scene = false;
+  photon_state_free(ctx->photons);
+
+  // ---- nodes and instances
+  std::vector<DNode> nodes(sc->n_nodes);
+  for (uint32_t i = 0; i < sc->n_nodes; i++) {
+    const rt_node& n = sc->nodes[i];
+    if (i == 0 ? n.parent != -1 : (n.parent < 0 || n.parent >= (int)i))
+      return fail(ctx, RT_ERR_INVALID, "nodes must be in depth-first order with parent < index");
+    std::memcpy(nodes[i].itm, n.itm.m, sizeof nodes[i].itm);
+    std::memcpy(nodes[i].tm, n.tm.m, sizeof nodes[i].tm);
+  }
+  std::vector<DInstance> inst;
+  for (uint32_t i = 0; i < sc->n_nodes; i++) {
+    const rt_node& n = sc->nodes[i];
+    if (n.prim_kind == RT_PRIM_NONE) continue;
+    if (n.prim_kind != RT_PRIM_SPHERE && n.prim_kind != RT_PRIM_PLANE && n.prim_kind != RT_PRIM_MESH)
+      return fail(ctx, RT_ERR_INVALID, "unknown primitive kind");
+    if (n.prim_kind == RT_PRIM_MESH && (n.mesh_id < 0 || n.mesh_id >= (int)sc->n_meshes))
+      return fail(ctx, RT_ERR_INVALID, "mesh index out of range");
+    DInstance I;
+    std::memset(&I, 0, sizeof I);
+    I.node = (int)i; I.prim = n.prim_kind; I.mesh = n.mesh_id;
+    I.mtl = (n.material_id >= 0 && n.material_id < (int)sc->n_materials) ? n.material_id : (int)sc->n_materials;
+    int chain[64], d = 0;
+    for (int k = (int)i; k >= 0 && d < 64; k = sc->nodes[k].parent) chain[d++] = k;
+    if (d > RT_MAX_CHAIN) return fail(ctx, RT_ERR_UNSUPPORTED, "scene graph deeper than 8 levels");
+    I.depth = d;
+    for (int k = 0; k < d; k++) I.chain[k] = chain[d - 1 - k];
+    // padded world bounds (only mesh instances are culled with them)
+    double lo[3], hi[3];
+    if (n.prim_kind == RT_PRIM_MESH) {
+      const rt_mesh& m = sc->meshes[n.mesh_id];
+      for (int k = 0; k < 3; k++) { lo[k] = m.bound_min[k]; hi[k] = m.bound_max[k]; }
+    } else {
+      lo[0] = lo[1] = -1; hi[0] = hi[1] = 1;
+      lo[2] = n.prim_kind == RT_PRIM_PLANE ? 0 : -1;
+      hi[2] = n.prim_kind == RT_PRIM_PLANE ? 0 : 1;
+    }
+    double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+    for (int c = 0; c < 8; c++) {
+      double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+      for (int k = d - 1; k >= 0; k--) {
+        const float* t = sc->nodes[I.chain[k]].tm.m;
+        double q[3];
+        for (int r = 0; r < 3; r++) q[r] = (double)t[r] * p[0] + (double)t[3 + r] * p[1] + (double)t[6 + r] * p[2] + (double)t[9 + r];
+        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+      }
+      for (int k = 0; k < 3; k++) { wlo[k] = std::min(wlo[k], p[k]); whi[k] = std::max(whi[k], p[k]); }
+    }
+    for (int k = 0; k < 3; k++) {
+      double pad = 1e-3 * (whi[k] - wlo[k]) + 1e-3 * std::max(std::fabs(wlo[k]), std::fabs(whi[k])) + 1e-4;
+      I.wmin[k] = (float)(wlo[k] - pad);
+      I.wmax[k] = (float)(whi[k] + pad);
+    }
+    inst.push_back(I);
+  }
+
+  // ---- meshes
+  std::vector<DMesh> meshes(sc->n_meshes);
+  std::vector<float4> bvh, tris;
+  std::vector<float> normals, uvw;
+  std::vector<uint32_t> nidx, uidx;
+  for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
+    const rt_mesh& m = sc->meshes[mi];
+    if (!m.positions || !m.normals || !m.pos_idx || !m.nrm_idx || !m.bvh || m.n_bvh_nodes == 0 || (m.n_faces && !m.bvh_elements))
+      return fail(ctx, RT_ERR_INVALID, "mesh with missing arrays");
+    for (size_t k = 0; k < 3 * (size_t)m.n_faces; k++) {
+      if (m.pos_idx[k] >= m.n_positions || m.nrm_idx[k] >= m.n_normals) return fail(ctx, RT_ERR_INVALID, "mesh index out of range");
+      if (m.uvw_idx && m.uvw && m.uvw_idx[k] >= m.n_uvw) return fail(ctx, RT_ERR_INVALID, "mesh uvw index out of range");
+    }
+    DMesh& D = meshes[mi];
+    std::memset(&D, 0, sizeof D);
+    MeshConv cv(m, bvh, tris);
+    uint32_t root;
+    if (!cv.convert(0, 0, root)) return fail(ctx, RT_ERR_INVALID, "mesh BVH: " + cv.err);
+    D.node_base = (uint32_t)cv.node_base;
+    D.tri_base = (uint32_t)cv.tri_base;
+    D.root_ref = root;
+    const rt_bvh_node& r = m.bvh[0];
+    for (int k = 0; k < 3; k++) { D.bounds[k] = r.bmin[k]; D.bounds[3 + k] = r.bmax[k]; }
+    D.nrm_base = (uint32_t)normals.size();
+    normals.insert(normals.end(), m.normals, m.normals + 3 * (size_t)m.n_normals);
+    D.nidx_base = (uint32_t)nidx.size();
+    nidx.insert(nidx.end(), m.nrm_idx, m.nrm_idx + 3 * (size_t)m.n_faces);
+    D.has_uvw = (m.uvw && m.uvw_idx) ? 1 : 0;
+    if (D.has_uvw) {
+      D.uvw_base = (uint32_t)uvw.size();
+      uvw.insert(uvw.end(), m.uvw, m.uvw + 3 * (size_t)m.n_uvw);
+      D.uidx_base = (uint32_t)uidx.size();
+      uidx.insert(uidx.end(), m.uvw_idx, m.uvw_idx + 3 * (size_t)m.n_faces);
+    }
+  }
+
+  // ---- materials, textures, lights
+  std::vector<DMaterial> mtls;
+  ctx->h_materials.clear();
+  auto check_tc = [&](const rt_tex_color& t) { return t.map < (int)sc->n_texmaps; };
+  for (uint32_t i = 0; i < sc->n_materials; i++) {
+    const rt_material& m = sc->materials[i];
+    if (!check_tc(m.diffuse) || !check_tc(m.specular) || !check_tc(m.emission) || !check_tc(m.reflection) ||
+        !check_tc(m.refraction) || m.glossiness.map >= (int)sc->n_texmaps)
+      return fail(ctx, RT_ERR_INVALID, "material texture map index out of range");
+    mtls.push_back(conv_mtl(m));
+    ctx->h_materials.push_back(m);
+  }
+  mtls.push_back(conv_mtl(default_material()));
+  ctx->h_materials.push_back(default_material());
+  std::vector<DTexmap> tms(sc->n_texmaps);
+  for (uint32_t i = 0; i < sc->n_texmaps; i++) {
+    const rt_texmap& t = sc->texmaps[i];
+    if (t.kind != RT_TEX_CHECKER && t.kind != RT_TEX_IMAGE) return fail(ctx, RT_ERR_INVALID, "unknown texture kind");
+    if (t.kind == RT_TEX_IMAGE && (t.image < 0 || t.image >= (int)sc->n_images)) return fail(ctx, RT_ERR_INVALID, "image index out of range");
+    if (!check_tc(t.color[0]) || !check_tc(t.color[1])) return fail(ctx, RT_ERR_INVALID, "checker colour map index out of range");
+    tms[i].kind = t.kind; tms[i].image = t.image;
+    std::memcpy(tms[i].itm, t.itm.m, sizeof tms[i].itm);
+    tms[i].color[0] = conv_tc(t.color[0]); tms[i].color[1] = conv_tc(t.color[1]);
+  }
+  if (!check_tc(sc->background) || !check_tc(sc->environment)) return fail(ctx, RT_ERR_INVALID, "background map index out of range");
+  std::vector<DImage> imgs(sc->n_images);
+  std::vector<uint8_t> texels;
+  for (uint32_t i = 0; i < sc->n_images; i++) {
+    const rt_image& im = sc->images[i];
+    if (!im.rgb || im.width <= 0 || im.height <= 0) return fail(ctx, RT_ERR_INVALID, "empty image");
+    imgs[i].offset = (uint32_t)texels.size();
+    imgs[i].width = im.width; imgs[i].height = im.height; imgs[i].pad = 0;
+    texels.insert(texels.end(), im.rgb, im.rgb + 3 * (size_t)im.width * im.height);
+  }
+  std::vector<DLight> lights(sc->n_lights);
+  ctx->lights.assign(sc->lights, sc->lights + sc->n_lights);
+  for (uint32_t i = 0; i < sc->n_lights; i++) {
+    const rt_light& l = sc->lights[i];
+    if (l.kind != RT_LIGHT_AMBIENT && l.kind != RT_LIGHT_DIRECT && l.kind != RT_LIGHT_POINT)
+      return fail(ctx, RT_ERR_INVALID, "unknown light kind");
+    lights[i].kind = l.kind;
+    std::memcpy(lights[i].intensity, l.intensity, 12);
+    std::memcpy(lights[i].position, l.position, 12);
+    std::memcpy(lights[i].direction, l.direction, 12);
+    lights[i].size = l.size; lights[i].attenuation = l.attenuation;
+  }
+  if (sc->n_lights > 250) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 250 lights");
+
+  // ---- Halton tables (values computed with the reference's float loop, rng.h:103-112)
+  const int n_gloss = 4096;
+  std::vector<float> hal(RT_HGLOSS + 2 * n_gloss);
+  for (int i = 0; i < 128; i++) {
+    hal[RT_H2 + i] = halton_ref(i, 2); hal[RT_H3 + i] = halton_ref(i, 3);
+    hal[RT_H5 + i] = halton_ref(i, 5); hal[RT_H7 + i] = halton_ref(i, 7);
+  }
+  for (int i = 0; i < 1000; i++) { hal[RT_HPHI + i] = halton_ref(i, 2); hal[RT_HTHETA + i] = halton_ref(i, 3); }
+  for (int i = 0; i < n_gloss; i++) { hal[RT_HGLOSS + i] = halton_ref(i, 2); hal[RT_HGLOSS + n_gloss + i] = halton_ref(i, 3); }
+
+  DScene& D = ctx->ds;
+  std::memset(&D, 0, sizeof D);
+  int rc;
+  if ((rc = upload(ctx, ctx->scene_mem, nodes, &D.nodes))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, inst, &D.inst))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, bvh, &D.bvh))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, tris, &D.tris))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, normals, &D.normals))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, nidx, &D.nrm_idx))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, uvw, &D.uvw))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, uidx, &D.uvw_idx))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, mtls, &D.materials))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, tms, &D.texmaps))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, imgs, &D.images))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, texels, &D.texels))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, lights, &D.lights))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, hal, &D.halton))) return rc;
+  D.n_inst = (int)inst.size();
+  D.n_lights = (int)lights.size();
+  D.n_materials = (int)sc->n_materials;
+  D.n_gloss = n_gloss;
+  D.background = conv_tc(sc->background);
+  D.environment = conv_tc(sc->environment);
+  ctx->camera = sc->camera;
+  ctx->n_nodes = (int)sc->n_nodes;
+  ctx->h_inst = inst;
+  ctx->has_scene = true;
+  return RT_OK;
+}
+
+int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (n == 0) return RT_OK;
+  if (!rays || !hits || n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "bad ray batch");
+  static_assert(sizeof(HitOut) == sizeof(rt_hit), "rt_hit layout");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<DevMem> tmp;
+  void *d_r, *d_h;
+  int rc;
+  if ((rc = alloc_dev(ctx, tmp, n * sizeof(rt_ray), &d_r)) || (rc = alloc_dev(ctx, tmp, n * sizeof(rt_hit), &d_h))) { free_pool(tmp); return rc; }
+  hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    LAUNCH(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(hits, d_h, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(tmp);
+  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (n == 0) return RT_OK;
+  if (!rays || !occluded || n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "bad ray batch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<DevMem> tmp;
+  void *d_r, *d_t = nullptr, *d_o;
+  int rc;
+  if ((rc = alloc_dev(ctx, tmp, n * sizeof(rt_ray), &d_r)) || (rc = alloc_dev(ctx, tmp, n, &d_o))) { free_pool(tmp); return rc; }
+  if (t_max && (rc = alloc_dev(ctx, tmp, n * sizeof(float), &d_t))) { free_pool(tmp); return rc; }
+  hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && t_max) e = hipMemcpyAsync(d_t, t_max, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    LAUNCH(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(occluded, d_o, n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(tmp);
+  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ rendering
+namespace {
+
+enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_GH = 2, CNT_GS = 3, CNT_N2 = 4, CNT_GQ = 5, CNT_PER_LEVEL = 8 };
+constexpr int MAX_LEVELS = 8;
+constexpr int CNT_OVERFLOW = MAX_LEVELS * CNT_PER_LEVEL;
+constexpr int CNT_ACTIVE = CNT_OVERFLOW + 1;
+constexpr int CNT_TOTAL = CNT_OVERFLOW + 8;
+
+struct Timer {
+  rt_context* ctx;
+  int kind;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  Timer(rt_context* c, int k) : ctx(c), kind(k), on(c->profile_on) {
+    if (!on) return;
+    auto take = [&]() {
+      hipEvent_t e;
+      if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+      else (void)hipEventCreate(&e);
+      return e;
+    };
+    a = take(); b = take();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  void stop(uint64_t items_slot) {
+    if (!on) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->ev_used.push_back({a, b, kind, items_slot});
+  }
+};
+
+// After a pass has been synchronised: fold event timings and per-level item counts into the profile.
+void collect_profile(rt_context* ctx, const std::vector<uint32_t>& counts) {
+  for (auto& e : ctx->ev_used) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      ctx->prof.ms[e.kind] += ms;
+      ctx->prof.launches[e.kind] += 1;
+      if (e.items_slot < counts.size()) ctx->prof.items[e.kind] += counts[e.items_slot];
+      else if (e.items_slot >= (1ull << 32)) ctx->prof.items[e.kind] += e.items_slot - (1ull << 32);
+    }
+    ctx->ev_pool.push_back(e.a);
+    ctx->ev_pool.push_back(e.b);
+  }
+  ctx->ev_used.clear();
+}
+
+struct FramePlan {
+  int W, H;
+  int levels;         // number of shading levels (max bounce depth + 1)
+  int branch;
+  uint32_t budget;    // camera samples per pass
+  int n_hard, n_soft; // light counts by shadow kind under these params
+  bool photons;
+};
+
+int ensure_frame(rt_context* ctx, const FramePlan& fp) {
+  size_t key[8] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft, (size_t)fp.photons};
+  if (!ctx->frame_mem.empty() && !std::memcmp(key, ctx->frame_key, sizeof key)) return RT_OK;
+  free_pool(ctx->frame_mem);
+  std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
+  double worst = 1;
+  for (int l = 1; l < fp.levels; l++) worst *= fp.branch;
+  size_t qcap = (size_t)std::min<double>((double)fp.budget * worst, 3.0e8);
+  int rc;
+  void* p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, CNT_TOTAL * sizeof(uint32_t), &p))) return rc;
+  ctx->d_counts = (uint32_t*)p;
+  for (int k = 0; k < 2; k++) {
+    RayQ& q = ctx->Q[k];
+    q.cap = (uint32_t)qcap;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q0 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q1 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q2 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q3 = (uint4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h0 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h1 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h2 = (float4*)p;
+    q.count = nullptr;
+  }
+  auto alloc_group = [&](GroupQ& g, size_t cap) {
+    g.cap = (uint32_t)std::max<size_t>(cap, 1);
+    int r;
+    void* pp;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g0 = (float4*)pp;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g1 = (float4*)pp;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g2 = (float4*)pp;
+    g.count = nullptr;
+    return (int)RT_OK;
+  };
+  if ((rc = alloc_group(ctx->GH, std::min<size_t>(qcap * (size_t)fp.n_hard, 0x7fffffffu)))) return rc;
+  if ((rc = alloc_group(ctx->GS, std::min<size_t>(qcap * (size_t)fp.n_soft, 0x7fffffffu)))) return rc;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.cap * 4, &p))) return rc;
+  ctx->d_list2 = (uint32_t*)p;
+  size_t gcap = fp.photons ? qcap : 1;
+  ctx->GQ.cap = (uint32_t)gcap;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.a = (float4*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
+  ctx->GQ.count = nullptr;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 16, &p))) return rc;
+  ctx->d_path_rad = (float4*)p;
+  size_t npx = (size_t)fp.W * fp.H;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_pixels = (uint32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 8, &p))) return rc; ctx->d_pixels2 = (uint32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_hit_node = (int32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_hit_face = (int32_t*)p;
+  std::memcpy(ctx->frame_key, key, sizeof key);
+  std::memset(ctx->pixel_key, 0, sizeof ctx->pixel_key);
+  ctx->path_budget = fp.budget;
+  return RT_OK;
+}
+
+// Pixel list of the requested 32x32 tiles (raytracer.h:46, RayTracer.cpp:103-115), walked in 8x8 blocks so that
+// one wavefront's 64 camera rays cover a compact screen patch.
+void build_pixel_list(const rt_render_params& P, int W, int H, std::vector<uint32_t>& out) {
+  const int tileSize = 32;
+  int tilesX = (W + tileSize - 1) / tileSize, tilesY = (H + tileSize - 1) / tileSize;
+  int total = tilesX * tilesY;
+  int stride = P.tile_stride > 0 ? P.tile_stride : 1;
+  out.clear();
+  for (int t = P.tile_begin, k = 0; t < total; t += stride, k++) {
+    if (P.tile_count > 0 && k >= P.tile_count) break;
+    if (t < 0) continue;
+    int x0 = (t % tilesX) * tileSize, y0 = (t / tilesX) * tileSize;
+    int x1 = std::min(x0 + tileSize, W), y1 = std::min(y0 + tileSize, H);
+    for (int by = y0; by < y1; by += 8)
+      for (int bx = x0; bx < x1; bx += 8)
+        for (int y = by; y < std::min(by + 8, y1); y++)
+          for (int x = bx; x < std::min(bx + 8, x1); x++) out.push_back((uint32_t)(y * W + x));
+  }
+}
+
+struct PassCounts {
+  std::vector<uint32_t> v;
+};
+
+template <bool CNT>
+int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bool any_soft, bool any_hard, bool photons,
+             const rt_render_params& RP) {
+  HIP_TRY(hipMemsetAsync(ctx->d_counts, 0, CNT_TOTAL * sizeof(uint32_t), ctx->stream));
+  uint32_t n0 = P.n_pix * (uint32_t)P.n_samples;
+  RayQ Qc = ctx->Q[0], Qn = ctx->Q[1];
+  Qc.count = ctx->d_counts + 0 * CNT_PER_LEVEL + CNT_Q0;
+  {
+    Timer t(ctx, RT_K_RAYGEN);
+    LAUNCH(k_raygen, n0, ctx->ds, P, F, Qc);
+    t.stop((1ull << 32) + n0);
+  }
+  double ub = n0;
+  int branch = 2 + (P.mc_bounces > 0 ? 1 : 0);
+  for (int lvl = 0; lvl < levels; lvl++) {
+    uint32_t* cbase = ctx->d_counts + lvl * CNT_PER_LEVEL;
+    uint32_t* cnext = ctx->d_counts + (lvl + 1) * CNT_PER_LEVEL;
+    Qn.count = (lvl + 1 < MAX_LEVELS) ? cnext + CNT_Q0 : cbase + CNT_Q1;
+    GroupQ GH = ctx->GH, GS = ctx->GS;
+    GatherQ GQ = ctx->GQ;
+    GH.count = cbase + CNT_GH; GS.count = cbase + CNT_GS; GQ.count = cbase + CNT_GQ;
+    uint32_t* n2 = cbase + CNT_N2;
+    uint64_t ubn = (uint64_t)std::min<double>(ub, (double)Qc.cap);
+    {
+      Timer t(ctx, RT_K_TRACE_CLOSEST);
+      LAUNCH(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, lvl);
+      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_Q0));
+    }
+    {
+      Timer t(ctx, RT_K_SHADE);
+      LAUNCH(k_shade<CNT>, ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_Q0));
+    }
+    if (any_hard) {
+      Timer t(ctx, RT_K_SHADOW);
+      LAUNCH(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, GH.cap), ctx->ds, P, F, GH);
+      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GH));
+    }
+    if (any_soft) {
+      Timer t(ctx, RT_K_SHADOW);
+      uint64_t gs_ub = std::min<uint64_t>(ubn * 4, GS.cap);
+      LAUNCH(k_shadow_soft1<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS);
+      LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
+      if (P.shadow_max > P.shadow_min) {
+        LAUNCH(k_shadow_soft2<CNT>, gs_ub * (uint64_t)(P.shadow_max - P.shadow_min), ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
+        LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
+      }
+      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GS));
+    }
+    if (photons) {
+      Timer t(ctx, RT_K_PHOTON_GATHER);
+      photon_gather_queue(ctx->photons, ctx->stream, ctx->max_blocks, GQ, F, RP, ubn);
+      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GQ));
+    }
+    std::swap(Qc, Qn);
+    ub *= branch;
+  }
+  {
+    Timer t(ctx, RT_K_ACCUM);
+    LAUNCH(k_accumulate, P.n_pix, P, F);
+    t.stop((1ull << 32) + P.n_pix);
+  }
+  return RT_OK;
+}
+
+int check_params(rt_context* ctx, const rt_render_params& P) {
+  if (P.sampler != RT_SAMPLER_PHILOX)
+    return fail(ctx, RT_ERR_UNSUPPORTED, "the device integrator draws from Philox streams only (RT_SAMPLER_PCG_HALTON is sequential per pixel)");
+  if (P.spp_max <= 0 || P.spp_min < 0 || P.spp_min > P.spp_max) return fail(ctx, RT_ERR_INVALID, "bad spp_min/spp_max");
+  if (P.max_bounces < 0 || P.max_bounces > 5 || P.mc_bounces < 0 || P.mc_bounces > 5) return fail(ctx, RT_ERR_INVALID, "bounce limits must be in 0..5");
+  if (P.mc_bounces > 0 && P.mc_samples != 1) return fail(ctx, RT_ERR_UNSUPPORTED, "mc_samples must be 1 (renderer.h:172)");
+  if (P.shadow_min <= 0 || P.shadow_max < P.shadow_min) return fail(ctx, RT_ERR_INVALID, "bad shadow_min/shadow_max");
+  if (P.sample_begin < 0 || P.sample_count < 0 || P.sample_begin + P.sample_count > 65536) return fail(ctx, RT_ERR_INVALID, "bad sample range");
+  return RT_OK;
+}
+
+// Adds the requested samples into d_accum (W*H*8 floats).  Writes AOVs into the context's device AOV buffers.
+int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_accum, bool track_progress) {
+  int rc = check_params(ctx, RP);
+  if (rc) return rc;
+  const rt_camera& c = ctx->camera;
+  int W = RP.width > 0 ? RP.width : c.width, H = RP.height > 0 ? RP.height : c.height;
+  if (W <= 0 || H <= 0 || (long long)W * H > (1ll << 28)) return fail(ctx, RT_ERR_INVALID, "bad image size");
+  int begin = RP.sample_begin;
+  int count = RP.sample_count > 0 ? RP.sample_count : RP.spp_max - begin;
+  if (count <= 0) return fail(ctx, RT_ERR_INVALID, "empty sample range");
+  bool adaptive = RP.spp_min < RP.spp_max && begin == 0 && count == RP.spp_max;
+
+  int n_hard = 0, n_soft = 0;
+  for (auto& l : ctx->lights) {
+    if (l.kind == RT_LIGHT_DIRECT) n_hard++;
+    else if (l.kind == RT_LIGHT_POINT) { if (l.size * RP.light_size_scale != 0.0f) n_soft++; else n_hard++; }
+  }
+  bool photons = RP.photons != 0 && RP.mc_bounces == 0;
+  bool photons_mixed = RP.photons != 0;  // below the MC depth the photon branch is taken (materials.cpp:313-322)
+  if (photons_mixed) {
+    rc = photon_ensure_built(ctx->photons, ctx, RP);
+    if (rc) return rc;
+  }
+  (void)photons;
+  FramePlan fp;
+  fp.W = W; fp.H = H;
+  fp.levels = std::max(RP.max_bounces, RP.mc_bounces) + 1;
+  if (fp.levels > MAX_LEVELS - 1) return fail(ctx, RT_ERR_UNSUPPORTED, "too many bounce levels");
+  fp.branch = 2 + (RP.mc_bounces > 0 ? 1 : 0);
+  fp.n_hard = n_hard; fp.n_soft = n_soft; fp.photons = photons_mixed;
+  // bytes of queue memory per camera sample in the worst case; keep the frame resources near 6 GB
+  double worst = std::pow((double)fp.branch, fp.levels - 1);
+  double per_path = worst * (2.0 * 112 + 48.0 * (n_hard + n_soft) + 4.0 * n_soft + (photons_mixed ? 48.0 : 0.0)) + 16;
+  double b = 6.0e9 / per_path;
+  uint32_t budget = (uint32_t)std::min<double>(std::max<double>(b, 65536.0), 4194304.0);
+  budget &= ~63u;
+  fp.budget = budget;
+  if ((rc = ensure_frame(ctx, fp))) return rc;
+
+  // pixel list
+  size_t pkey[6] = {(size_t)W, (size_t)H, (size_t)RP.tile_begin + 1, (size_t)RP.tile_count, (size_t)RP.tile_stride, 1};
+  if (std::memcmp(pkey, ctx->pixel_key, sizeof pkey)) {
+    build_pixel_list(RP, W, H, ctx->h_pixels);
+    if (!ctx->h_pixels.empty())
+      HIP_TRY(hipMemcpyAsync(ctx->d_pixels, ctx->h_pixels.data(), ctx->h_pixels.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(ctx->pixel_key, pkey, sizeof pkey);
+  }
+  uint32_t n_pix_total = (uint32_t)ctx->h_pixels.size();
+  if (n_pix_total == 0) return RT_OK;
+  HIP_TRY(hipMemsetAsync(ctx->d_hit_node, 0xff, (size_t)W * H * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_hit_face, 0xff, (size_t)W * H * 4, ctx->stream));
+
+  PassP P;
+  std::memset(&P, 0, sizeof P);
+  {  // RayTracer.cpp:15-22 and 95-101
+    float Zx = -c.dir[0], Zy = -c.dir[1], Zz = -c.dir[2];
+    float Yx = c.up[0], Yy = c.up[1], Yz = c.up[2];
+    P.Z[0] = Zx; P.Z[1] = Zy; P.Z[2] = Zz;
+    P.Y[0] = Yx; P.Y[1] = Yy; P.Y[2] = Yz;
+    P.X[0] = Yy * Zz - Yz * Zy; P.X[1] = Yz * Zx - Yx * Zz; P.X[2] = Yx * Zy - Yy * Zx;
+    P.pos[0] = c.pos[0]; P.pos[1] = c.pos[1]; P.pos[2] = c.pos[2];
+    P.l = c.focaldist;
+    P.camW = (float)W; P.camH = (float)H;
+    P.wh = (float)(2.0f * P.l * std::tan(((double)c.fov * RT_PI_D / 180.0) / 2.0f));
+    P.ww = P.wh * (P.camW / P.camH);
+    P.dof = c.dof;
+  }
+  P.W = W; P.H = H;
+  P.jitter = RP.pixel_jitter;
+  P.seed_lo = RP.seed_lo; P.seed_hi = RP.seed_hi;
+  P.max_bounces = RP.max_bounces; P.mc_bounces = RP.mc_bounces; P.mc_samples = RP.mc_samples;
+  P.shadow_min = RP.shadow_min; P.shadow_max = RP.shadow_max;
+  P.light_size_scale = RP.light_size_scale;
+  P.photons = photons_mixed ? 1 : 0;
+  P.srgb = c.srgb;
+  P.aov_sample = begin;
+  P.spp_min = RP.spp_min; P.spp_max = RP.spp_max; P.adaptive = adaptive ? 1 : 0;
+  P.adaptive_threshold = RP.adaptive_threshold;
+
+  FrameBufs F;
+  F.path_rad = ctx->d_path_rad;
+  F.accum = d_accum;
+  F.hit_node = ctx->d_hit_node;
+  F.hit_face = ctx->d_hit_face;
+  F.overflow = ctx->d_counts + CNT_OVERFLOW;
+  F.counters = ctx->d_counters;
+
+  std::vector<uint32_t> counts(CNT_TOTAL);
+  auto finish_pass = [&](uint64_t paths) -> int {
+    HIP_TRY(hipMemcpyAsync(counts.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    collect_profile(ctx, counts);
+    if (counts[CNT_OVERFLOW]) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow");
+    if (ctx->counters_on) ctx->host_paths += paths;
+    return RT_OK;
+  };
+  auto pass = [&](const uint32_t* pixels, uint32_t n_pix, int sbase, int ns) -> int {
+    PassP Pp = P;
+    Pp.n_pix = n_pix; Pp.sample_base = sbase; Pp.n_samples = ns;
+    FrameBufs Ff = F;
+    Ff.pixels = pixels;
+    int r = ctx->counters_on ? run_pass<true>(ctx, Pp, Ff, fp.levels, n_soft > 0, n_hard > 0, photons_mixed, RP)
+                             : run_pass<false>(ctx, Pp, Ff, fp.levels, n_soft > 0, n_hard > 0, photons_mixed, RP);
+    if (r) return r;
+    return finish_pass((uint64_t)n_pix * ns);
+  };
+
+  if (!adaptive) {
+    // fixed sample count: chunks of pixels x chunks of samples
+    uint32_t pix_chunk = std::min<uint32_t>(n_pix_total, budget);
+    for (uint32_t p0 = 0; p0 < n_pix_total; p0 += pix_chunk) {
+      uint32_t np = std::min(pix_chunk, n_pix_total - p0);
+      int ns_max = std::max<int>(1, (int)(budget / np));
+      for (int s = 0; s < count; s += ns_max) {
+        int ns = std::min(ns_max, count - s);
+        if ((rc = pass(ctx->d_pixels + p0, np, begin + s, ns))) return rc;
+      }
+      if (track_progress) ctx->pixels_done += np;
+    }
+  } else {
+    // Adaptive: the stop test runs after every sample i >= spp_min (RayTracer.cpp:180-198).  First spp_min+1 samples
+    // for every pixel, then small chunks for the pixels still active; k_accumulate applies the test sample by sample
+    // and ignores samples past a pixel's stopping point, so the result equals the sequential loop's.
+    uint32_t pix_chunk = std::min<uint32_t>(n_pix_total, budget);
+    const int first = std::min(RP.spp_min + 1, RP.spp_max);
+    for (uint32_t p0 = 0; p0 < n_pix_total; p0 += pix_chunk) {
+      uint32_t np = std::min(pix_chunk, n_pix_total - p0);
+      int ns_max = std::max<int>(1, (int)(budget / np));
+      for (int s = 0; s < first; s += ns_max)
+        if ((rc = pass(ctx->d_pixels + p0, np, s, std::min(ns_max, first - s)))) return rc;
+      // continue with the active subset
+      const uint32_t* cur = ctx->d_pixels + p0;
+      uint32_t ncur = np;
+      uint32_t* bufs[2] = {ctx->d_pixels2, ctx->d_pixels2 + (size_t)W * H};
+      int which = 0;
+      int s = first;
+      while (s < RP.spp_max) {
+        HIP_TRY(hipMemsetAsync(ctx->d_counts + CNT_ACTIVE, 0, 4, ctx->stream));
+        PassP Pp = P;
+        Pp.n_pix = ncur;
+        FrameBufs Ff = F;
+        Ff.pixels = cur;
+        LAUNCH(k_compact_active, ncur, Pp, Ff, bufs[which], ctx->d_counts + CNT_ACTIVE);
+        uint32_t nact = 0;
+        HIP_TRY(hipMemcpyAsync(&nact, ctx->d_counts + CNT_ACTIVE, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (nact == 0) break;
+        cur = bufs[which];
+        ncur = nact;
+        which ^= 1;
+        int ns = std::min<int>(std::min<int>(8, RP.spp_max - s), std::max<int>(1, (int)(budget / ncur)));
+        if ((rc = pass(cur, ncur, s, ns))) return rc;
+        s += ns;
+      }
+      if (track_progress) ctx->pixels_done += np;
+    }
+  }
+  return RT_OK;
+}
+
+int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d_accum, rt_framebuffer* fb) {
+  const rt_camera& c = ctx->camera;
+  int W = RP.width > 0 ? RP.width : c.width, H = RP.height > 0 ? RP.height : c.height;
+  size_t npx = (size_t)W * H;
+  if (fb->on_device) {
+    LAUNCH(k_resolve, npx, W, H, c.srgb, d_accum, (uint8_t*)fb->rgb8, (float*)fb->radiance, (int32_t*)fb->sample_count);
+    if (fb->hit_node) HIP_TRY(hipMemcpyAsync(fb->hit_node, ctx->d_hit_node, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fb->hit_face) HIP_TRY(hipMemcpyAsync(fb->hit_face, ctx->d_hit_face, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+  }
+  std::vector<DevMem> tmp;
+  void *d_rgb = nullptr, *d_rad = nullptr, *d_sc = nullptr;
+  int rc = RT_OK;
+  if (fb->rgb8 && (rc = alloc_dev(ctx, tmp, npx * 3, &d_rgb))) { free_pool(tmp); return rc; }
+  if (fb->radiance && (rc = alloc_dev(ctx, tmp, npx * 16, &d_rad))) { free_pool(tmp); return rc; }
+  if (fb->sample_count && (rc = alloc_dev(ctx, tmp, npx * 4, &d_sc))) { free_pool(tmp); return rc; }
+  LAUNCH(k_resolve, npx, W, H, c.srgb, d_accum, (uint8_t*)d_rgb, (float*)d_rad, (int32_t*)d_sc);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && fb->rgb8) e = hipMemcpyAsync(fb->rgb8, d_rgb, npx * 3, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->radiance) e = hipMemcpyAsync(fb->radiance, d_rad, npx * 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->sample_count) e = hipMemcpyAsync(fb->sample_count, d_sc, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->hit_node && ctx->d_hit_node) e = hipMemcpyAsync(fb->hit_node, ctx->d_hit_node, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->hit_face && ctx->d_hit_face) e = hipMemcpyAsync(fb->hit_face, ctx->d_hit_face, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(tmp);
+  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int render_blocking(rt_context* ctx, const rt_render_params& RP, rt_framebuffer* fb, bool track) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  const rt_camera& c = ctx->camera;
+  int W = RP.width > 0 ? RP.width : c.width, H = RP.height > 0 ? RP.height : c.height;
+  if (W <= 0 || H <= 0) return fail(ctx, RT_ERR_INVALID, "bad image size");
+  DevMem acc;
+  HIP_TRY(hipMalloc(&acc.p, (size_t)W * H * 8 * sizeof(float)));
+  hipError_t e = hipMemsetAsync(acc.p, 0, (size_t)W * H * 8 * sizeof(float), ctx->stream);
+  int rc = e == hipSuccess ? RT_OK : fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  if (!rc) rc = accumulate_internal(ctx, RP, (float*)acc.p, track);
+  if (!rc) rc = resolve_internal(ctx, RP, (const float*)acc.p, fb);
+  (void)hipStreamSynchronize(ctx->stream);
+  acc.release();
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render(rt_context* ctx, const rt_render_params* params, rt_framebuffer* fb) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (!params || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
+  if (ctx->worker.joinable()) ctx->worker.join();
+  return render_blocking(ctx, *params, fb, false);
+}
+
+int rt_render_begin(rt_context* ctx, const rt_render_params* params, rt_framebuffer* fb) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (!params || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
+  if (ctx->worker.joinable()) ctx->worker.join();
+  ctx->pixels_done = 0;
+  ctx->finished = 0;
+  rt_render_params P = *params;
+  rt_framebuffer F = *fb;
+  ctx->worker = std::thread([ctx, P, F]() mutable {
+    ctx->async_status = render_blocking(ctx, P, &F, true);
+    ctx->finished = 1;
+  });
+  return RT_OK;
+}
+
+int rt_render_poll(rt_context* ctx, int64_t* pixels_done, int* finished) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (pixels_done) *pixels_done = ctx->pixels_done.load();
+  if (finished) *finished = ctx->finished.load();
+  return RT_OK;
+}
+
+int rt_render_wait(rt_context* ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (ctx->worker.joinable()) ctx->worker.join();
+  return ctx->async_status;
+}
+
+int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, void* d_accum) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (!params || !d_accum) return fail(ctx, RT_ERR_INVALID, "null argument");
+  if (ctx->worker.joinable()) ctx->worker.join();
+  HIP_TRY(hipSetDevice(ctx->device));
+  return accumulate_internal(ctx, *params, (float*)d_accum, false);
+}
+
+int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_accum, rt_framebuffer* fb) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (!params || !d_accum || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return resolve_internal(ctx, *params, (const float*)d_accum, fb);
+}
+
+int rt_photons_build(rt_context* ctx, const rt_render_params* params) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (!params) return fail(ctx, RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->photons.built = false;
+  return photon_ensure_built(ctx->photons, ctx, *params);
+}
+
+int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
+  if (!ctx || !n) return RT_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return photon_download(ctx->photons, ctx, which, out, capacity, n);
+}
+
+int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius, float ellipticity,
+                     int k, float* irradiance) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!P || !N || !irradiance) return fail(ctx, RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return photon_gather_api(ctx->photons, ctx, which, P, N, n, radius, ellipticity, k, irradiance);
+}
+
+int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t width, int32_t height, const float* albedo,
+               const float* normal) {
+  if (!ctx) return RT_ERR_INVALID;
+  return fail(ctx, RT_ERR_UNSUPPORTED, "denoise filter not built yet");
+}
+
+int rt_counters_enable(rt_context* ctx, int enable) {
+  if (!ctx) return RT_ERR_INVALID;
+  ctx->counters_on = enable != 0;
+  return RT_OK;
+}
+int rt_counters_reset(rt_context* ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof(DCounters)));
+  ctx->host_paths = 0;
+  return RT_OK;
+}
+int rt_counters_get(rt_context* ctx, rt_counters* out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  static_assert(sizeof(DCounters) == sizeof(rt_counters), "counter layout");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out, ctx->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost));
+  out->paths += ctx->host_paths;
+  return RT_OK;
+}
+int rt_profile_enable(rt_context* ctx, int enable) {
+  if (!ctx) return RT_ERR_INVALID;
+  ctx->profile_on = enable != 0;
+  return RT_OK;
+}
+int rt_profile_reset(rt_context* ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  std::memset(&ctx->prof, 0, sizeof ctx->prof);
+  return RT_OK;
+}
+int rt_profile_get(rt_context* ctx, rt_profile* out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  *out = ctx->prof;
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from raytracer_amd import default_params, rays_from_arrays
+
+
+def params(width, height, spp=1, jitter=0, bounces=0, photons=0, light_scale=1.0, mc=0, seed=1):
+    p = default_params()
+    p.width, p.height = width, height
+    p.spp_min = p.spp_max = spp
+    p.pixel_jitter = jitter
+    p.max_bounces = bounces
+    p.photons = photons
+    p.light_size_scale = light_scale
+    p.mc_bounces = mc
+    p.seed_lo = seed
+    return p
+
+
+def rel_colour_diff(a, b, floor=1e-3):
+    """max |a-b| / max(|b|, floor) over rgb"""
+    a = a[..., :3].astype(np.float64)
+    b = b[..., :3].astype(np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def psnr8(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)
+
+
+def random_rays(n, seed, origin_box=((-20, -70, -2), (20, 30, 26)), target_box=((-16, -12, -1), (16, 21, 25))):
+    """Seeded rays from points in origin_box towards points in target_box (unnormalised directions)."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(origin_box[0], np.float32), np.array(origin_box[1], np.float32)
+    o = (lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)).astype(np.float32)
+    lo, hi = np.array(target_box[0], np.float32), np.array(target_box[1], np.float32)
+    t = (lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)).astype(np.float32)
+    d = (t - o).astype(np.float32)
+    scale = (0.25 + 2.0 * rng.random((n, 1), dtype=np.float32)).astype(np.float32)
+    return rays_from_arrays(o, d * scale)
+
+
+def assert_hits_equal(gpu, cpu, what=""):
+    """Bit-exact on decisions (node / face / light / front / miss) and on z; p and N to 1e-5 relative, uvw to 1e-5 abs."""
+    for k in ("node", "face", "light"):
+        assert np.array_equal(gpu[k], cpu[k]), f"{what}: {k} differs at {np.flatnonzero(gpu[k] != cpu[k])[:8]}"
+    hit = (cpu["node"] >= 0) | (cpu["light"] >= 0)
+    assert np.array_equal(gpu["front"][hit], cpu["front"][hit]), f"{what}: front flag differs"
+    assert np.array_equal(gpu["z"], cpu["z"]), f"{what}: z differs (max {np.abs(gpu['z'][hit] - cpu['z'][hit]).max()})"
+    surf = cpu["node"] >= 0
+    for k in ("p", "N"):
+        d = np.abs(gpu[k][surf] - cpu[k][surf])
+        s = np.maximum(np.abs(cpu[k][surf]), 1.0)
+        assert (d / s).max(initial=0) <= 1e-5, f"{what}: {k} differs by {(d / s).max()}"
+    d = np.abs(gpu["uvw"][surf] - cpu["uvw"][surf])
+    assert d.max(initial=0) <= 1e-5, f"{what}: uvw differs by {d.max()}"
