@@ -56,7 +56,7 @@ def cpu_baseline(scene, target_seconds=12.0):
     t0 = time.perf_counter()
     _, cnt = orc.render(p, cores, want_counters=True)
     t1 = time.perf_counter() - t0
-    spp = int(max(1, min(SPP_PER_STEP, target_seconds / max(t1, 1e-3))))
+    spp = int(max(1, min(8 * SPP_PER_STEP, target_seconds / max(t1, 1e-3))))
     p.sample_count = spp
     t0 = time.perf_counter()
     _, cnt = orc.render(p, cores, want_counters=True)
@@ -88,7 +88,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from raytracer_amd import Renderer, Scene
+    from raytracer_amd import Renderer, Scene, distributed
     scene = Scene.load(SCENE)
     r = Renderer(local_rank)
     r.LoadScene(scene)
@@ -98,9 +98,9 @@ def main():
     def step():
         accum.zero_()
         torch.cuda.synchronize()
-        r.render_accumulate(p, accum.data_ptr())   # blocking: returns when this rank's samples are in `accum`
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # sample-split exchange, RCCL over xGMI
+        # blocking render of this rank's sample range into `accum`, then the sample-split exchange:
+        # one RCCL sum-reduce of the accumulators to rank 0 over xGMI
+        distributed.render_partition(r, p, accum)
 
     # one counted, untimed step: algorithmic work per step
     r.counters(enable=True, reset=True)

@@ -1,0 +1,167 @@
+"""CPU-side logic check of the integrator: the HOST EMULATION build of raytracer_amd/csrc (tests/_emu, g++ -DRT_EMU,
+single-threaded) against the recursive CPU oracle.  Exercises the queue-per-stage unrolling of the reference's
+recursion, the shadow-group phases, adaptive sampling, partitioning and the batched trace API where no GPU exists;
+the same comparisons run against the real HIP library in test_gpu_*.py."""
+import numpy as np
+import pytest
+
+import emu_ffi
+import oracle_ffi
+from common import assert_hits_equal, params, psnr8, random_rays, rel_colour_diff
+from conftest import scene_path
+from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, Scene
+
+TEXTURED = """<xml><scene>
+  <object type="plane" name="floor" material="chk"> <scale value="20"/> </object>
+  <object type="sphere" name="ball" material="glass"> <scale value="3"/> <translate x="-4" z="3"/> </object>
+  <object type="sphere" name="mirror" material="mir"> <scale value="3"/> <translate x="4" z="3"/> </object>
+  <object type="sphere" name="white" material="wht"> <translate x="0" y="-4" z="1"/> </object>
+  <material type="blinn" name="chk">
+    <diffuse texture="checkerboard"> <color1 r="0.9" g="0.2" b="0.2"/>
+      <color2 value="0.8" texture="checkerboard"> <color1 r="0.1" g="0.1" b="0.8"/> <scale value="0.125"/> </color2>
+      <scale value="0.1"/> <rotate angle="30" z="1"/> </diffuse>
+    <specular value="0.2"/> <glossiness value="50"/> <reflection value="0.3"/>
+  </material>
+  <material type="blinn" name="glass"> <diffuse value="0.05"/> <specular value="0.6"/> <glossiness value="40"/>
+    <refraction value="0.85" index="1.4"/> <absorption r="0.05" g="0.01" b="0.02"/> </material>
+  <material type="blinn" name="mir"> <diffuse value="0.1"/> <specular value="0.8"/> <glossiness value="8"/> <reflection value="0.8"/> </material>
+  <material type="microfacet" name="wht"/>
+  <light type="direct"> <intensity value="0.6"/> <direction x="1" y="1" z="-2"/> </light>
+  <light type="point"> <intensity value="60" r="1" g="0.9" b="0.8"/> <position x="0" y="-2" z="9"/> <size value="1.5"/> <attenuation value="1"/> </light>
+  <light type="ambient"> <intensity value="0.2"/> </light>
+  <background r="0.2" g="0.3" b="0.5"/>
+  <environment value="0.7" texture="checkerboard"> <color1 r="0.3" g="0.5" b="0.9"/> <color2 r="0.9" g="0.9" b="0.9"/> <scale value="0.05"/> </environment>
+</scene>
+<camera gamma="sRGB"> <position x="0" y="-18" z="6"/> <target x="0" y="0" z="2"/> <up x="0" y="0" z="1"/> <fov value="40"/>
+  <focaldist value="18"/> <dof value="0.15"/> <width value="96"/> <height value="64"/> </camera></xml>"""
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_ffi.EmuRenderer()
+
+
+@pytest.mark.parametrize("name", ["spheres_room.xml", "cornell_box.xml", "c2_mesh_room.xml"])
+def test_trace_api(emu, name):
+    scene = Scene.load(scene_path(name))
+    emu.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    rays = random_rays(3000, seed=21)
+    for side in (RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK):
+        assert_hits_equal(emu.TraceRay(rays, side), orc.trace_closest(rays, side), name)
+    tmax = (0.2 + 2.0 * np.random.default_rng(2).random(len(rays))).astype(np.float32)
+    assert np.array_equal(emu.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax))
+
+
+@pytest.mark.parametrize("name", ["spheres_room.xml", "cornell_box.xml", "c2_mesh_room.xml"])
+def test_config1_frames_bit_exact_ids(emu, name):
+    scene = Scene.load(scene_path(name))
+    emu.LoadScene(scene)
+    p = params(160, 120, spp=1, jitter=0, bounces=0, light_scale=0.0)
+    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
+    assert rel_colour_diff(g.radiance, c.radiance) <= 1e-6
+
+
+@pytest.mark.parametrize("name,spp,bounces", [("cornell_box.xml", 3, 3), ("c2_mesh_room.xml", 2, 3)])
+def test_recursion_unrolled_into_queues(emu, name, spp, bounces):
+    scene = Scene.load(scene_path(name))
+    emu.LoadScene(scene)
+    p = params(96, 54, spp=spp, jitter=1, bounces=bounces)
+    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 2e-5
+    assert psnr8(g.img, c.img) >= 50
+
+
+def test_textures_dof_environment_direct_light_white_material(emu):
+    scene = Scene.from_string(TEXTURED)
+    assert scene.desc.n_texmaps == 3
+    emu.LoadScene(scene)
+    p = params(96, 64, spp=3, jitter=1, bounces=3)
+    g, (c, cnt) = emu.Render(p), oracle_ffi.OracleScene(scene).render(p, want_counters=True)
+    assert cnt["tex_evals"] > 0 and cnt["rays_secondary"] > 0
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
+    assert np.array_equal(g.hit_node, c.hit_node)
+
+
+def test_monte_carlo_indirect(emu):
+    scene = Scene.from_string(TEXTURED)
+    emu.LoadScene(scene)
+    p = params(64, 48, spp=2, jitter=1, bounces=2, mc=2)
+    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
+
+
+def test_adaptive_sampling_matches_sequential_loop(emu):
+    """RayTracer.cpp:136-204: the stop test after every sample >= spp_min; Q1/Q2 positions."""
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    emu.LoadScene(scene)
+    p = params(48, 27, jitter=1, bounces=2)
+    p.spp_min, p.spp_max = 4, 24
+    p.adaptive_threshold = 0.02
+    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert np.array_equal(g.sample_count, c.sample_count)
+    assert c.sample_count.min() == 5 and c.sample_count.max() == 24 and len(np.unique(c.sample_count)) > 3
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 2e-5
+
+
+def test_tile_and_sample_partitions_reproduce_the_frame(emu):
+    """partition logic with G 'virtual devices' — tile split is exact, sample split sums to the frame."""
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    emu.LoadScene(scene)
+    W, H = 80, 72
+    p = params(W, H, spp=4, jitter=1, bounces=1)
+    full = emu.Render(p)
+    G = 3
+    acc = np.zeros(W * H * 8, np.float32)
+    for r in range(G):
+        q = params(W, H, spp=4, jitter=1, bounces=1)
+        q.tile_begin, q.tile_stride = r, G
+        emu.render_accumulate(q, acc.ctypes.data)
+    tiles = emu.resolve(p, acc.ctypes.data)
+    assert np.array_equal(tiles.radiance, full.radiance) and np.array_equal(tiles.img, full.img)
+    acc[:] = 0
+    for r in range(2):
+        q = params(W, H, spp=4, jitter=1, bounces=1)
+        q.sample_begin, q.sample_count = 2 * r, 2
+        emu.render_accumulate(q, acc.ctypes.data)
+    split = emu.resolve(p, acc.ctypes.data)
+    assert np.allclose(split.radiance, full.radiance, rtol=1e-6, atol=1e-7)
+    # and the oracle agrees on what a sample range is
+    q = params(W, H, spp=4, jitter=1, bounces=1)
+    q.sample_begin, q.sample_count = 2, 2
+    o = oracle_ffi.OracleScene(scene).render(q)
+    acc[:] = 0
+    emu.render_accumulate(q, acc.ctypes.data)
+    assert np.abs(emu.resolve(q, acc.ctypes.data).radiance - o.radiance).max() <= 2e-5
+
+
+def test_counters_agree_with_oracle_on_ray_counts(emu):
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    emu.LoadScene(scene)
+    p = params(64, 36, spp=2, jitter=1, bounces=3)
+    p.skip_zero_weight = 1
+    emu.counters(enable=True, reset=True)
+    emu.Render(p)
+    g = emu.counters()
+    emu.counters(enable=False)
+    _, c = oracle_ffi.OracleScene(scene).render(p, want_counters=True)
+    for k in ("rays_primary", "rays_secondary", "shades", "paths"):
+        assert g[k] == c[k], k
+    assert g["rays_shadow"] <= c["rays_shadow"]  # the device skips shadow rays whose unshadowed term is exactly zero
+
+
+def test_error_paths(emu):
+    scene = Scene.load(scene_path("spheres_room.xml"))
+    emu.LoadScene(scene)
+    p = params(16, 16)
+    p.sampler = 1
+    with pytest.raises(RuntimeError, match="Philox"):
+        emu.Render(p)
+    p = params(16, 16)
+    p.max_bounces = 9
+    with pytest.raises(RuntimeError):
+        emu.Render(p)
+    fresh = emu_ffi.EmuRenderer()
+    with pytest.raises(RuntimeError, match="no scene"):
+        fresh.TraceRay(random_rays(4, 1))
