@@ -206,7 +206,8 @@ def load_core():
     global _core
     if _core is not None:
         return _core
-    path = os.path.join(LIB_DIR, "librtcore.so")
+    # RTCORE_LIB: developer knob to A/B another HIP build of the same sources (kernel experiments); never a CPU library
+    path = os.environ.get("RTCORE_LIB") or os.path.join(LIB_DIR, "librtcore.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension must be built (no CPU fallback exists)")
     _preload_torch_hip_runtime()

@@ -35,19 +35,19 @@ RT_HD bool nonzero(V3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
 
 // ------------------------------------------------------------------ device scene
 
-struct DNode {          // one scene-graph node: Transformation::itm / tm (scene.h:155-156), column-major 3x4
-  float itm[12];
-  float tm[12];
-};
-
-struct DInstance {      // a node that carries a primitive, with its chain of ancestors
-  int32_t node;         // node index (== rt_node index)
+struct DInstance {      // a node that carries a primitive (64 bytes); its chain of transforms lives in DScene::xf
   int32_t prim;         // RT_PRIM_*
   int32_t mesh;
   int32_t mtl;          // material index; n_materials = the default Blinn
-  int32_t depth;        // number of entries in chain
-  int32_t chain[RT_MAX_CHAIN];  // node indices root .. this node
-  float wmin[3], wmax[3];       // padded world-space bounds (culling of mesh instances only)
+  int32_t node;         // node index (== rt_node index)
+  int32_t depth;        // levels in the chain root .. this node
+  int32_t parent_key;   // node index of the parent (identifies the chain prefix), -1 for a root-level instance
+  int32_t xf_off;       // float offset into DScene::xf of this instance's chain: depth x { itm[12], tm[12] }, root first
+  int32_t pad0;
+  float wmin[3];        // padded world-space bounds (culling of mesh instances only)
+  float pad1;
+  float wmax[3];
+  float pad2;
 };
 
 struct DMesh {
@@ -81,8 +81,8 @@ struct DLight {
 };
 
 struct DScene {
-  const DNode* nodes;
   const DInstance* inst;
+  const float* xf;      // transform chains, see DInstance::xf_off
   const DMesh* meshes;
   const float4* bvh;
   const float4* tris;
@@ -155,15 +155,18 @@ template <> struct Cnt<false> {
 };
 
 // ------------------------------------------------------------------ transforms (scene.h:170-189)
-RT_HD V3 xf_point(const float* m, V3 p) {
+template <class M>
+RT_HD V3 xf_point(M m, V3 p) {
   return v3(m[0] * p.x + m[3] * p.y + m[6] * p.z + m[9], m[1] * p.x + m[4] * p.y + m[7] * p.z + m[10],
             m[2] * p.x + m[5] * p.y + m[8] * p.z + m[11]);
 }
-RT_HD V3 xf_dir(const float* m, V3 p) {
+template <class M>
+RT_HD V3 xf_dir(M m, V3 p) {
   return v3(m[0] * p.x + m[3] * p.y + m[6] * p.z, m[1] * p.x + m[4] * p.y + m[7] * p.z,
             m[2] * p.x + m[5] * p.y + m[8] * p.z);
 }
-RT_HD V3 xf_tmul(const float* m, V3 p) {  // (3x3)^T * p : NormalTransformFrom with itm
+template <class M>
+RT_HD V3 xf_tmul(M m, V3 p) {  // (3x3)^T * p : NormalTransformFrom with itm
   return v3(m[0] * p.x + m[1] * p.y + m[2] * p.z, m[3] * p.x + m[4] * p.y + m[5] * p.z,
             m[6] * p.x + m[7] * p.y + m[8] * p.z);
 }
@@ -288,6 +291,33 @@ RT_DEV bool box_test(V3 p, V3 inv, float b0, float b1, float b2, float b3, float
   return tmax >= tmin && tmax >= 0.0f;
 }
 
+// Same test with v_min/v_max (min3/max3).  Bit-identical decisions whenever no slab product is NaN, i.e. whenever
+// every component of inv is finite (NaN needs 0 * inf: a zero direction component AND an origin exactly on that slab
+// plane); rays with a non-finite inv component take box_test above.  (-0 vs +0 results cannot change a comparison.)
+RT_DEV bool box_test_fast(V3 p, V3 inv, float b0, float b1, float b2, float b3, float b4, float b5, float& tmin_out) {
+  float t1 = (b0 - p.x) * inv.x;
+  float t2 = (b3 - p.x) * inv.x;
+  float t3 = (b1 - p.y) * inv.y;
+  float t4 = (b4 - p.y) * inv.y;
+  float t5 = (b2 - p.z) * inv.z;
+  float t6 = (b5 - p.z) * inv.z;
+  float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+  float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+  tmin_out = tmin;
+  return tmax >= tmin && tmax >= 0.0f;
+}
+template <bool FAST>
+RT_DEV bool box_test_sel(V3 p, V3 inv, float b0, float b1, float b2, float b3, float b4, float b5, float& tmin_out) {
+  if (FAST) return box_test_fast(p, inv, b0, b1, b2, b3, b4, b5, tmin_out);
+  return box_test(p, inv, b0, b1, b2, b3, b4, b5, tmin_out);
+}
+RT_DEV bool inv_is_finite(V3 inv) {
+#ifdef RT_NO_FASTBOX
+  return false;
+#endif
+  return fabsf(inv.x) <= RT_BIG && fabsf(inv.y) <= RT_BIG && fabsf(inv.z) <= RT_BIG;
+}
+
 // Möller–Trumbore with precomputed edges — TriObj::IntersectTriangle, objects.cpp:193-231.
 // (v0, e1 = v1 - v0, e2 = v2 - v0) are the same float values the reference computes per test.
 RT_DEV bool tri_test(V3 p, V3 d, V3 v0, V3 e1, V3 e2, float& t, float& u, float& v) {
@@ -323,12 +353,12 @@ struct MeshHit {
 // depth-first order wins (child 2 beats child 1, :331-337) and inside a leaf the earlier triangle wins (:294).
 // Traversal is ordered and pruned against `t_bound` (hits at or beyond the current global best cannot win:
 // the scene-graph compare is a strict <, RayTracer.cpp:387,404).
-template <bool CNT>
-RT_DEV bool mesh_closest(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_bound, MeshHit& out,
-                         uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+template <bool CNT, bool FAST>
+RT_DEV bool mesh_closest_t(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_bound, MeshHit& out,
+                           uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   float tm;
   cnt.node();
-  if (!box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
+  if (!box_test_sel<FAST>(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
   const float4* nodes = S.bvh + M.node_base;
   const float4* tris = S.tris + M.tri_base;
   float best_t = RT_BIG;
@@ -360,8 +390,8 @@ RT_DEV bool mesh_closest(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, fl
     float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
     float tl, tr;
     cnt.node(2);
-    bool hl = box_test(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-    bool hr = box_test(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+    bool hl = box_test_sel<FAST>(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+    bool hr = box_test_sel<FAST>(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
     float bound = prune_bound(best_t < t_bound ? best_t : t_bound);
     hl = hl && tl <= bound;
     hr = hr && tr <= bound;
@@ -385,13 +415,20 @@ RT_DEV bool mesh_closest(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, fl
   return true;
 }
 
-// TriObj::TraceBVHNodeShadow (objects.cpp:341-371): true iff some triangle of a visited leaf has t in (0.002, t_max).
 template <bool CNT>
-RT_DEV bool mesh_any(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_max, uint32_t* stk, uint32_t stride,
-                     Cnt<CNT>& cnt) {
+RT_DEV bool mesh_closest(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_bound, MeshHit& out,
+                         uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  if (inv_is_finite(inv)) return mesh_closest_t<CNT, true>(S, M, p, d, inv, t_bound, out, stk, stride, cnt);
+  return mesh_closest_t<CNT, false>(S, M, p, d, inv, t_bound, out, stk, stride, cnt);
+}
+
+// TriObj::TraceBVHNodeShadow (objects.cpp:341-371): true iff some triangle of a visited leaf has t in (0.002, t_max).
+template <bool CNT, bool FAST>
+RT_DEV bool mesh_any_t(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_max, uint32_t* stk, uint32_t stride,
+                       Cnt<CNT>& cnt) {
   float tm;
   cnt.node();
-  if (!box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
+  if (!box_test_sel<FAST>(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)) return false;
   const float4* nodes = S.bvh + M.node_base;
   const float4* tris = S.tris + M.tri_base;
   float bound = prune_bound(t_max);
@@ -414,8 +451,8 @@ RT_DEV bool mesh_any(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float 
     float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
     float tl, tr;
     cnt.node(2);
-    bool hl = box_test(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl) && tl <= bound;
-    bool hr = box_test(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr) && tr <= bound;
+    bool hl = box_test_sel<FAST>(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl) && tl <= bound;
+    bool hr = box_test_sel<FAST>(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr) && tr <= bound;
     uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
     if (hl && hr) {
       stk[(sp++) * stride] = cr;
@@ -432,10 +469,18 @@ RT_DEV bool mesh_any(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float 
   return false;
 }
 
+template <bool CNT>
+RT_DEV bool mesh_any(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, float t_max, uint32_t* stk, uint32_t stride,
+                     Cnt<CNT>& cnt) {
+  if (inv_is_finite(inv)) return mesh_any_t<CNT, true>(S, M, p, d, inv, t_max, stk, stride, cnt);
+  return mesh_any_t<CNT, false>(S, M, p, d, inv, t_max, stk, stride, cnt);
+}
+
 // PointLight::IntersectRay, objects.cpp:377-413 (int radius, double arithmetic)
-RT_DEV bool light_sphere(const DLight& L, V3 p, V3 d, float zbest, float& t_out, bool& front) {
-  int r = (int)L.size;
-  V3 oc = p - v3(L.position[0], L.position[1], L.position[2]);
+template <class LP>
+RT_DEV bool light_sphere(LP Lp, V3 p, V3 d, float zbest, float& t_out, bool& front) {
+  int r = (int)Lp->size;
+  V3 oc = p - v3(Lp->position[0], Lp->position[1], Lp->position[2]);
   float eps = 0.002f;
   double a = (double)dot(d, d);
   double b = 2.0 * (double)dot(oc, d);
@@ -468,13 +513,33 @@ struct Hit {            // HitInfo (scene.h:74-90) in world space before SetHit
   bool front;
 };
 
-RT_DEV void ray_to_instance(const DScene& S, const DInstance& I, V3& p, V3& d) {
-  for (int k = 0; k < I.depth; k++) {  // Node::ToNodeCoords down the chain (RayTracer.cpp:377)
-    const float* itm = S.nodes[I.chain[k]].itm;
-    V3 np = xf_point(itm, p);
-    V3 nd = xf_dir(itm, d);
-    p = np; d = nd;
+// Walks the instance table in depth-first order keeping the ray transformed to the CURRENT PARENT's space: siblings
+// share it, so each instance costs one Node::ToNodeCoords (RayTracer.cpp:377) instead of one per chain level.  The
+// arithmetic per level is the reference's (same matrices, same order), only repeated work is dropped.  Everything
+// here is wave-uniform control flow over scalar-loaded table entries.
+struct ParentRay {
+  int key;
+  V3 p, d;
+};
+template <class IP, class XP>
+RT_DEV void ray_to_instance(IP I, XP xf, V3 o, V3 dir, ParentRay& pr, V3& p, V3& d) {
+  int depth = I->depth, off = I->xf_off, pk = I->parent_key;
+#ifdef RT_NO_PARENT_CACHE
+  pr.key = -2;
+#endif
+  if (pk != pr.key) {
+    V3 cp = o, cd = dir;
+    for (int k = 0; k + 1 < depth; k++) {
+      XP m = xf + off + 24 * k;
+      V3 np = xf_point(m, cp);
+      V3 nd = xf_dir(m, cd);
+      cp = np; cd = nd;
+    }
+    pr.key = pk; pr.p = cp; pr.d = cd;
   }
+  XP m = xf + off + 24 * (depth - 1);
+  p = xf_point(m, pr.p);
+  d = xf_dir(m, pr.d);
 }
 
 // Renderer::TraceRay -> RayTracer::TraverseTree (RayTracer.cpp:373-435): closest hit over every instanced
@@ -487,27 +552,32 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
   MeshHit best_mh;
   best_mh.t = 0; best_mh.u = 0; best_mh.v = 0; best_mh.key = 0; best_mh.face = 0;
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
+  RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
+  ParentRay pr;
+  pr.key = -2; pr.p = o; pr.d = dir;
   for (int i = 0; i < S.n_inst; i++) {
-    const DInstance& I = S.inst[i];
-    if (I.prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
-      float tm;         // hit the mesh, so the result is unchanged)
-      if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    RT_UTYPE(DInstance)* I = inst + i;
+    int prim = I->prim;
+    V3 p, d;
+    ray_to_instance(I, xf, o, dir, pr, p, d);
+    if (prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
+      float tm;       // hit the mesh, so the result is unchanged)
+      if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
     }
-    V3 p = o, d = dir;
-    ray_to_instance(S, I, p, d);
     cnt.inst();
     float t;
     bool front;
-    if (I.prim == 1) {
+    if (prim == 1) {
       cnt.sphere();
       if (sphere_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
-    } else if (I.prim == 2) {
+    } else if (prim == 2) {
       cnt.plane();
       if (plane_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
-    } else if (I.prim == 3) {
+    } else if (prim == 3) {
       V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
       MeshHit mh;
-      if (mesh_closest<CNT>(S, S.meshes[I.mesh], p, d, inv, best_t, mh, stk, stride, cnt) && mh.t < best_t) {
+      if (mesh_closest<CNT>(S, S.meshes[I->mesh], p, d, inv, best_t, mh, stk, stride, cnt) && mh.t < best_t) {
         best_t = mh.t; best_inst = i; best_mh = mh;
       }
     }
@@ -517,9 +587,14 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
   bool any = false;
   if (best_inst >= 0) {
     any = true;
-    const DInstance& I = S.inst[best_inst];
+    const DInstance& I = S.inst[best_inst];  // per-lane index: ordinary loads
+    const float* chain = S.xf + I.xf_off;
     V3 p = o, d = dir;
-    ray_to_instance(S, I, p, d);
+    for (int k = 0; k < I.depth; k++) {
+      V3 np = xf_point(chain + 24 * k, p);
+      V3 nd = xf_dir(chain + 24 * k, d);
+      p = np; d = nd;
+    }
     V3 hp, hn, uvw;
     bool front = best_front;
     if (I.prim == 1) {  // objects.cpp:37-43
@@ -553,15 +628,15 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
       hit.face = (int32_t)best_mh.face;
     }
     for (int k = I.depth - 1; k >= 0; k--) {  // Node::FromNodeCoords back up the chain (scene.h:184-189)
-      const DNode& n = S.nodes[I.chain[k]];
-      hp = xf_point(n.tm, hp);
-      hn = xf_tmul(n.itm, hn);
+      hp = xf_point(chain + 24 * k + 12, hp);
+      hn = xf_tmul(chain + 24 * k, hn);
     }
     hit.p = hp; hit.N = hn; hit.uvw = uvw; hit.z = best_t; hit.inst = best_inst; hit.front = front;
   }
+  RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);
   for (int l = 0; l < S.n_lights; l++) {  // RayTracer.cpp:413-432
-    const DLight& L = S.lights[l];
-    if (L.kind == 3 && L.size > 0.0f) {
+    RT_UTYPE(DLight)* L = lights + l;
+    if (L->kind == 3 && L->size > 0.0f) {
       float t;
       bool front;
       if (light_sphere(L, o, dir, RT_BIG, t, front)) {
@@ -583,27 +658,34 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 template <bool CNT>
 RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
+  RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
+  ParentRay pr;
+  pr.key = -2; pr.p = o; pr.d = dir;
+  bool occluded = false;
   for (int i = 0; i < S.n_inst; i++) {
-    const DInstance& I = S.inst[i];
-    if (I.prim == 3) {
+    RT_UTYPE(DInstance)* I = inst + i;
+    int prim = I->prim;
+    V3 p, d;
+    ray_to_instance(I, xf, o, dir, pr, p, d);
+    if (occluded) continue;  // lanes that already found an occluder idle; the loop itself stays wave-uniform
+    if (prim == 3) {
       float tm;
-      if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+      if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
     }
-    V3 p = o, d = dir;
-    ray_to_instance(S, I, p, d);
     cnt.inst();
-    if (I.prim == 1) {
+    if (prim == 1) {
       cnt.sphere();
-      if (sphere_any(p, d, t_max)) return true;
-    } else if (I.prim == 2) {
+      occluded = sphere_any(p, d, t_max);
+    } else if (prim == 2) {
       cnt.plane();
-      if (plane_any(p, d, t_max)) return true;
-    } else if (I.prim == 3) {
+      occluded = plane_any(p, d, t_max);
+    } else if (prim == 3) {
       V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-      if (mesh_any<CNT>(S, S.meshes[I.mesh], p, d, inv, t_max, stk, stride, cnt)) return true;
+      occluded = mesh_any<CNT>(S, S.meshes[I->mesh], p, d, inv, t_max, stk, stride, cnt);
     }
   }
-  return false;
+  return occluded;
 }
 
 // ------------------------------------------------------------------ textures (texture.cpp:106-140, scene.h:312-397)

@@ -23,8 +23,9 @@ struct RayQ {
   float4* h0;  // hit p.xyz, z
   float4* h1;  // hit N.xyz, instance (int bits)
   float4* h2;  // hit uvw.xyz, flags (bit0 front, bits 8.. light+1)
-  uint32_t* count;
-  uint32_t cap;
+  uint32_t* counts;  // nseg segment lengths, RT_CSTRIDE words apart
+  uint32_t segcap;   // entries per segment; entry index = segment * segcap + position
+  uint32_t nseg;
 };
 // meta word: tree position (12 bits) | bounce << 12 (3 bits) | secondary << 15 | reshade << 16
 #define RT_META(nid, bounce, sec, resh) ((uint32_t)(nid) | ((uint32_t)(bounce) << 12) | ((uint32_t)(sec) << 15) | ((uint32_t)(resh) << 16))
@@ -33,16 +34,18 @@ struct GroupQ {  // one record per (shade point, light) whose unshadowed contrib
   float4* g0;    // P.xyz, light index
   float4* g1;    // weight * unshadowed BRDF term rgb, path slot
   float4* g2;    // disc offsets rx, ry (lights.cpp:25-26), lit-sample counter, unused
-  uint32_t* count;
-  uint32_t cap;
+  uint32_t* counts;
+  uint32_t segcap;
+  uint32_t nseg;
 };
 
 struct GatherQ {  // photon-map lookups deferred to k_photon_gather (materials.cpp:315-322)
   float4* a;      // P.xyz, path slot
   float4* b;      // N.xyz, which map (0 global, 1 caustics)
   float4* c;      // weight * kd / pi rgb
-  uint32_t* count;
-  uint32_t cap;
+  uint32_t* counts;
+  uint32_t segcap;
+  uint32_t nseg;
 };
 
 struct PassP {
@@ -75,14 +78,92 @@ struct FrameBufs {
   DCounters* counters;
 };
 
-RT_DEV uint32_t queue_push(uint32_t* count, uint32_t cap, uint32_t* overflow) {
-  uint32_t i = rt_atomic_add_u32(count, 1u);
-  if (i >= cap) {
+// ---- segmented queues ------------------------------------------------------------------------------
+// One returning atomic on a single counter word saturates near 90 M/s on this chip, and a kernel that appends once
+// per wave per iteration is bound by exactly that.  Every queue is therefore split into nseg (64) segments with
+// their own length word (128 bytes apart): wave g appends to segment g % nseg, with ONE atomic per wave per append
+// site (ballot + mbcnt ranks), and consumer kernels give each wave one segment to walk.  Segments stay dense, the
+// contention per word drops 64x, and because children land in their parent's segment the worst-case length of a
+// segment is exactly (worst-case queue length) / nseg — no slack, no holes.
+#define RT_CSTRIDE 32u
+#define RT_NONE 0xFFFFFFFFu
+#ifndef RT_EMU
+#define RT_WAVE 64u
+RT_DEV uint32_t rt_lane() { return threadIdx.x & 63u; }
+RT_DEV uint32_t rt_wave_id() { return RT_TID >> 6; }
+RT_DEV uint32_t rt_num_waves() { return RT_NTHREADS >> 6; }
+RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0) return RT_NONE;
+  uint32_t n = (uint32_t)__popcll(mask);
+  uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)rt_lane() == leader) base = atomicAdd(counts + seg * RT_CSTRIDE, n);
+  base = (uint32_t)__shfl((int)base, leader);
+  if (!pred) return RT_NONE;
+  uint32_t pos = base + rank;
+  if (pos >= segcap) {
     *overflow = 1u;
-    return 0xFFFFFFFFu;
+    return RT_NONE;
   }
-  return i;
+  return seg * segcap + pos;
 }
+#else
+#define RT_WAVE 1u
+RT_DEV uint32_t rt_lane() { return 0u; }
+RT_DEV uint32_t rt_wave_id() { return 0u; }
+RT_DEV uint32_t rt_num_waves() { return 1u; }
+RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
+  if (!pred) return RT_NONE;
+  uint32_t pos = counts[seg * RT_CSTRIDE]++;
+  if (pos >= segcap) {
+    *overflow = 1u;
+    return RT_NONE;
+  }
+  return seg * segcap + pos;
+}
+#endif
+
+// Which segment(s) this wave walks, and with which stride.  With G >= nseg waves, wave g takes segment g % nseg
+// together with the G / nseg - 1 other waves of that residue; with fewer waves each takes several segments.
+struct SegWalk {
+  uint32_t s, s_step, r, R;
+};
+RT_DEV void seg_walk_init(SegWalk& w, uint32_t nseg) {
+  uint32_t G = rt_num_waves(), g = rt_wave_id();
+  if (G >= nseg) {
+    w.R = G / nseg;
+    w.s = g % nseg;
+    w.s_step = nseg;
+    w.r = g / nseg;
+    if (w.r >= w.R) w.s = nseg;
+  } else {
+    w.R = 1;
+    w.s = g;
+    w.s_step = G;
+    w.r = 0;
+  }
+}
+// Loop over `mult` work items per queue entry; inside: seg_e (item number within the segment), seg_valid,
+// seg_base_ (index of the segment's first entry), sw_.s (segment).  All lanes of a wave run the same iterations.
+#define RT_SEG_BEGIN(counts_, nseg_, segcap_, mult_)                                                        \
+  {                                                                                                         \
+    SegWalk sw_;                                                                                            \
+    seg_walk_init(sw_, (nseg_));                                                                            \
+    for (; sw_.s < (nseg_); sw_.s += sw_.s_step) {                                                          \
+      uint32_t seg_n_ = (counts_)[sw_.s * RT_CSTRIDE];                                                      \
+      if (seg_n_ > (segcap_)) seg_n_ = (segcap_);                                                           \
+      const unsigned long long seg_items_ = (unsigned long long)seg_n_ * (unsigned long long)(mult_);       \
+      const uint32_t seg_base_ = sw_.s * (segcap_);                                                         \
+      for (unsigned long long e0_ = (unsigned long long)sw_.r * RT_WAVE; e0_ < seg_items_;                  \
+           e0_ += (unsigned long long)sw_.R * RT_WAVE) {                                                    \
+        const unsigned long long seg_e = e0_ + rt_lane();                                                   \
+        const bool seg_valid = seg_e < seg_items_;
+#define RT_SEG_END \
+  }                \
+  }                \
+  }
 
 RT_DEV float two_pi_times(float x) { return (float)(2.0 * RT_PI_D * (double)x); }  // `2.0f * M_PI * x` promotes to double
 
@@ -128,27 +209,36 @@ RT_KERNEL(k_raygen, DScene S, PassP P, FrameBufs F, RayQ Q) {
     V3 worldPixel = X * pixelPos.x + Y * pixelPos.y + Z * pixelPos.z;
     V3 origin = v3(P.pos[0], P.pos[1], P.pos[2]) + worldCamera;
     V3 dir = worldPixel - worldCamera;
-    Q.q0[idx] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-    Q.q1[idx] = make_float4(dir.x, dir.y, dir.z, 1.0f);
-    Q.q2[idx] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    // 64-path tiles (8x8 pixels of one sample) are dealt round-robin to the queue segments
+    uint32_t tile = idx / 64u;
+    uint32_t qi = (tile % Q.nseg) * Q.segcap + (tile / Q.nseg) * 64u + (idx % 64u);
+    Q.q0[qi] = make_float4(origin.x, origin.y, origin.z, 1.0f);
+    Q.q1[qi] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+    Q.q2[qi] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     uint4 m;
     m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
-    Q.q3[idx] = m;
+    Q.q3[qi] = m;
     F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  if (RT_TID == 0) *Q.count = total;
+  uint32_t tiles = (total + 63u) / 64u;
+  for (uint32_t sgm = RT_TID; sgm < Q.nseg; sgm += RT_NTHREADS) {
+    uint32_t nt = tiles > sgm ? (tiles - sgm + Q.nseg - 1u) / Q.nseg : 0u;
+    uint32_t cnt = nt * 64u;
+    if (nt && (tiles - 1u) % Q.nseg == sgm) cnt -= tiles * 64u - total;  // the last tile may be partial
+    Q.counts[sgm * RT_CSTRIDE] = cnt;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ trace
 template <bool CNT>
 RT_DEV void trace_closest_body(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, int level, uint32_t* stk, uint32_t stride) {
-  uint32_t n = *Q.count;
-  if (n > Q.cap) n = Q.cap;
   Cnt<CNT> cnt;
   uint32_t traced = 0;
-  for (uint32_t idx = RT_TID; idx < n; idx += RT_NTHREADS) {
+  RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
+    if (!seg_valid) continue;
+    uint32_t idx = seg_base_ + (uint32_t)seg_e;
     uint4 m = Q.q3[idx];
-    if (m.w & (1u << 16)) continue;  // re-shade entry: hit record was written by k_shade (lights.cpp:172-183)
+    if (m.w & (1u << 16)) continue;        // re-shade entry: hit record was written by k_shade (lights.cpp:172-183)
     float4 a = Q.q0[idx], b = Q.q1[idx];
     Hit h;
     traced++;
@@ -162,7 +252,7 @@ RT_DEV void trace_closest_body(const DScene& S, const PassP& P, const FrameBufs&
       F.hit_node[m.y] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
       F.hit_face[m.y] = h.light >= 0 ? -1 : h.face;
     }
-  }
+  RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     cnt.flush_closest(F.counters);
@@ -260,205 +350,240 @@ RT_DEV V3 absorb(V3 c, V3 ab, float dist) {  // materials.cpp:255-259
   return c;
 }
 
+struct ChildRay {
+  V3 o, d, w;
+  uint32_t meta;
+};
+RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs, uint32_t slot, uint32_t pixel, uint32_t sample) {
+  QN.q0[ci] = make_float4(c.o.x, c.o.y, c.o.z, c.w.x);
+  QN.q1[ci] = make_float4(c.d.x, c.d.y, c.d.z, c.w.y);
+  QN.q2[ci] = make_float4(mabs.x, mabs.y, mabs.z, c.w.z);
+  uint4 cm;
+  cm.x = slot; cm.y = pixel; cm.z = sample; cm.w = c.meta;
+  QN.q3[ci] = cm;
+}
+
+// Every lane of a wave runs every queue-append site of an iteration (predicated), so the per-wave chunk state of
+// wave_push stays uniform; see WavePush.
 template <bool CNT>
 RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
-  uint32_t n = *Q.count;
-  if (n > Q.cap) n = Q.cap;
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
-  for (uint32_t idx = RT_TID; idx < n; idx += RT_NTHREADS) {
-    float4 q0 = Q.q0[idx], q1 = Q.q1[idx], q2 = Q.q2[idx];
-    uint4 m = Q.q3[idx];
-    float4 h0 = Q.h0[idx], h1 = Q.h1[idx], h2 = Q.h2[idx];
-    V3 w = v3(q0.w, q1.w, q2.w);
-    V3 pabs = v3(q2.x, q2.y, q2.z);
-    V3 rdir = v3(q1.x, q1.y, q1.z);
+  RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);
+  RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
+    const uint32_t oseg = sw_.s % QN.nseg;  // children and shadow work stay in the parent's segment
+    uint32_t idx = seg_base_ + (uint32_t)seg_e;
+    bool valid = seg_valid;
+    uint4 m;
+    m.x = m.y = m.z = 0; m.w = 0;
+    if (valid) m = Q.q3[idx];
     uint32_t slot = m.x, pixel = m.y;
     uint32_t nid = m.w & 0xFFFu, bounce = (m.w >> 12) & 7u;
     bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
-    int inst = (int)__float_as_uint(h1.w);
-    uint32_t flags = __float_as_uint(h2.w);
-    int light = (int)((flags >> 8) & 0xFFFFu) - 1;
-    bool front = flags & 1u;
-    float z = h0.w;
 
-    if (inst < 0 && light < 0) {  // miss
-      if (bounce == 0) {          // RayTracer.cpp:253-258
-        float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
-        float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
-        add_radiance(F, slot, w * eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt));
-      } else {                    // lights.cpp:204-208, dist = BIGFLOAT
-        V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
-        add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
-      }
-      continue;
-    }
-    if (light >= 0) {
-      if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
-        const DLight& L = S.lights[light];
-        V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
-        add_radiance(F, slot, w * c);
-      } else {                    // lights.cpp:199-202
-        add_radiance(F, slot, w * absorb(v3(1, 1, 1), pabs, z));
-      }
-      continue;
-    }
-
-    // SamplerInfo::SetHit, renderer.h:142-150
+    bool surface = false;
     ShadePt sp;
-    float zs = z * length(rdir);
-    sp.N = normalized(v3(h1.x, h1.y, h1.z));
-    V3 nd = normalized(rdir);
-    sp.V = -nd;
-    sp.P = v3(h0.x, h0.y, h0.z);
-    sp.uvw = v3(h2.x, h2.y, h2.z);
-    sp.front = front;
-    sp.pixel = pixel;
-    sp.nid = nid;
-    sp.sample = (int)m.z;
-    if (bounce > 0) {  // lights.cpp:194 and materials.cpp:255-259 / 277-281, applied to this subtree's weight
-      float dist = reshade ? 0.0f : (front ? zs : 0.0f);
-      w = absorb(w, pabs, dist);
-    }
-    n_shades++;
-    const DInstance& I = S.inst[inst];
-    const DMaterial& M = S.materials[I.mtl];
-    if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
-      add_radiance(F, slot, w);
-      continue;
-    }
-    // materials.cpp:231-236
-    V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
-    V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
-    V3 kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
-    V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
-    float alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
-    V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
-    float diffScalar = (float)(1 / RT_PI_D);
-    float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
-    V3 cKd = kd * diffScalar;
-    V3 cKs = ks * specScalar;
-    V3 fullReflection = reflection;
-    V3 mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
-    bool can_bounce = (int)bounce < P.max_bounces;
-    float r0[4], r1[4];
-    bool have_r0 = false, have_r1 = false;
+    sp.P = sp.N = sp.V = sp.uvw = v3(0, 0, 0);
+    sp.front = true; sp.pixel = pixel; sp.nid = nid; sp.sample = (int)m.z;
+    V3 w = v3(0, 0, 0), mabs = v3(0, 0, 0), cKd = v3(0, 0, 0), cKs = v3(0, 0, 0), kd = v3(0, 0, 0);
+    float alpha = 0.0f, zs = 0.0f;
+    float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
+    ChildRay c_refr, c_refl, c_mc;
+    bool p_refr = false, p_refl = false, p_mc = false, p_gather = false, refl_below = false;
+    c_refr.o = c_refr.d = c_refr.w = c_refl.o = c_refl.d = c_refl.w = c_mc.o = c_mc.d = c_mc.w = v3(0, 0, 0);
+    c_refr.meta = c_refl.meta = c_mc.meta = 0;
+    V3 wk = v3(0, 0, 0);
 
-    if (M.ior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
-      float iorRatio = (1.0f - M.ior) / (1.0f + M.ior);
-      V3 fresnel = refraction * (iorRatio * iorRatio);
-      fullReflection = fullReflection + fresnel;
-      V3 wc = w * (refraction * (v3(1, 1, 1) - fullReflection));
-      if (nonzero(wc)) {
-        shade_draws(P, sp, 0, r0); have_r0 = true;
-        shade_draws(P, sp, 1, r1); have_r1 = true;
-        V3 o, d;
-        refract_ray(S, sp, M.ior, M.glossiness.v, r0, r1, o, d);
-        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
-        if (ci != 0xFFFFFFFFu) {
-          QN.q0[ci] = make_float4(o.x, o.y, o.z, wc.x);
-          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
-          QN.q2[ci] = make_float4(mabs.x, mabs.y, mabs.z, wc.z);
-          uint4 cm;
-          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
-          QN.q3[ci] = cm;
+    if (valid) {
+      float4 q0 = Q.q0[idx], q1 = Q.q1[idx], q2 = Q.q2[idx];
+      float4 h0 = Q.h0[idx];
+      h1 = Q.h1[idx];
+      h2 = Q.h2[idx];
+      w = v3(q0.w, q1.w, q2.w);
+      V3 pabs = v3(q2.x, q2.y, q2.z);
+      V3 rdir = v3(q1.x, q1.y, q1.z);
+      int inst = (int)__float_as_uint(h1.w);
+      uint32_t flags = __float_as_uint(h2.w);
+      int light = (int)((flags >> 8) & 0xFFFFu) - 1;
+      bool front = flags & 1u;
+      float z = h0.w;
+      if (inst < 0 && light < 0) {  // miss
+        if (bounce == 0) {          // RayTracer.cpp:253-258
+          float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
+          float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
+          add_radiance(F, slot, w * eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt));
+        } else {                    // lights.cpp:204-208, dist = BIGFLOAT
+          V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
+          add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
         }
-      }
-    }
-    if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
-      V3 wc = w * reflection;
-      if (nonzero(wc)) {
-        if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
-        V3 d = reflect_dir(S, sp, M.glossiness.v, r0[2], r0[3]);
-        bool below = dot(d, sp.N) < 0;  // lights.cpp:174: re-shade the same point with the new view direction
-        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
-        if (ci != 0xFFFFFFFFu) {
-          QN.q0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, wc.x);
-          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
-          QN.q2[ci] = make_float4(mabs.x, mabs.y, mabs.z, wc.z);
-          uint4 cm;
-          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 2, bounce + 1, 1, below ? 1 : 0);
-          QN.q3[ci] = cm;
-          if (below) {
-            QN.h0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, zs);
-            QN.h1[ci] = make_float4(sp.N.x, sp.N.y, sp.N.z, h1.w);
-            QN.h2[ci] = h2;
+      } else if (light >= 0) {
+        if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
+          const DLight& L = S.lights[light];
+          V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
+          add_radiance(F, slot, w * c);
+        } else {                    // lights.cpp:199-202
+          add_radiance(F, slot, w * absorb(v3(1, 1, 1), pabs, z));
+        }
+      } else {
+        // SamplerInfo::SetHit, renderer.h:142-150
+        zs = z * length(rdir);
+        sp.N = normalized(v3(h1.x, h1.y, h1.z));
+        V3 nd = normalized(rdir);
+        sp.V = -nd;
+        sp.P = v3(h0.x, h0.y, h0.z);
+        sp.uvw = v3(h2.x, h2.y, h2.z);
+        sp.front = front;
+        if (bounce > 0) {  // lights.cpp:194 and materials.cpp:255-259 / 277-281, applied to this subtree's weight
+          float dist = reshade ? 0.0f : (front ? zs : 0.0f);
+          w = absorb(w, pabs, dist);
+        }
+        n_shades++;
+        const DMaterial& M = S.materials[S.inst[inst].mtl];
+        if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
+          add_radiance(F, slot, w);
+        } else {
+          surface = true;
+          // materials.cpp:231-236
+          V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
+          V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
+          kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
+          V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
+          alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
+          V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
+          float diffScalar = (float)(1 / RT_PI_D);
+          float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
+          cKd = kd * diffScalar;
+          cKs = ks * specScalar;
+          V3 fullReflection = reflection;
+          mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
+          bool can_bounce = (int)bounce < P.max_bounces;
+          float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+          bool have_r0 = false, have_r1 = false;
+          float mior = M.ior, mgloss = M.glossiness.v;
+
+          if (mior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
+            float iorRatio = (1.0f - mior) / (1.0f + mior);
+            V3 fresnel = refraction * (iorRatio * iorRatio);
+            fullReflection = fullReflection + fresnel;
+            V3 wc = w * (refraction * (v3(1, 1, 1) - fullReflection));
+            if (nonzero(wc)) {
+              shade_draws(P, sp, 0, r0); have_r0 = true;
+              shade_draws(P, sp, 1, r1); have_r1 = true;
+              refract_ray(S, sp, mior, mgloss, r0, r1, c_refr.o, c_refr.d);
+              c_refr.w = wc;
+              c_refr.meta = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
+              p_refr = true;
+            }
           }
+          if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
+            V3 wc = w * reflection;
+            if (nonzero(wc)) {
+              if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
+              c_refl.d = reflect_dir(S, sp, mgloss, r0[2], r0[3]);
+              c_refl.o = sp.P;
+              c_refl.w = wc;
+              refl_below = dot(c_refl.d, sp.N) < 0;  // lights.cpp:174: re-shade the same point with the new view direction
+              c_refl.meta = RT_META(nid * 4 + 2, bounce + 1, 1, refl_below ? 1 : 0);
+              p_refl = true;
+            }
+          }
+          V3 local = emission;
+          if (P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
+            V3 wc = w * kd;
+            if (nonzero(wc)) {
+              if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
+              int hi = (sp.sample * P.mc_samples) % 1000;
+              float u1 = fmodf(S.halton[RT_HPHI + hi] + r1[2], 1.0f);
+              float u2 = fmodf(S.halton[RT_HTHETA + hi] + r1[3], 1.0f);
+              float r = sqrtf(u1);
+              float phi = two_pi_times(u2);
+              float x = r * cosf(phi), y = r * sinf(phi), zz = sqrtf(1.0f - u1);
+              V3 t, b;
+              orthonormals(sp.N, t, b);
+              c_mc.d = normalized((x * t) + (y * b) + (zz * sp.N));
+              c_mc.o = sp.P;
+              c_mc.w = wc;
+              c_mc.meta = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
+              p_mc = true;
+            }
+          } else if (P.photons) {  // materials.cpp:315-322
+            wk = w * ((float)(1.0f / RT_PI_D) * kd);
+            p_gather = nonzero(wk);
+          }
+          add_radiance(F, slot, w * local);
         }
       }
     }
+
+    // ---- queue appends (all lanes of the wave pass through here)
+    uint32_t ci = seg_push(p_refr, QN.counts, oseg, QN.segcap, F.overflow);
+    if (ci != RT_NONE) write_child(QN, ci, c_refr, mabs, slot, pixel, m.z);
+    ci = seg_push(p_refl, QN.counts, oseg, QN.segcap, F.overflow);
+    if (ci != RT_NONE) {
+      write_child(QN, ci, c_refl, mabs, slot, pixel, m.z);
+      if (refl_below) {
+        QN.h0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, zs);
+        QN.h1[ci] = make_float4(sp.N.x, sp.N.y, sp.N.z, h1.w);
+        QN.h2[ci] = h2;
+      }
+    }
+    ci = seg_push(p_mc, QN.counts, oseg, QN.segcap, F.overflow);
+    if (ci != RT_NONE) write_child(QN, ci, c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
 
     // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
     for (int li = 0; li < S.n_lights; li++) {
-      const DLight& L = S.lights[li];
-      if (L.kind == 1) continue;  // ambient is accumulated and never added
-      V3 lightDir, inten = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
-      bool soft = false;
-      if (L.kind == 2) {  // lights.h:45
-        lightDir = -v3(L.direction[0], L.direction[1], L.direction[2]);
-      } else {            // lights.cpp:62-71
-        V3 dl = v3(L.position[0], L.position[1], L.position[2]) - sp.P;
-        float dist = length(dl);
-        lightDir = normalized(dl);
-        if (L.attenuation != 0.0f) inten = inten / (dist * dist);
-        soft = (L.size * P.light_size_scale) != 0.0f;
-      }
-      V3 h = normalized(lightDir + sp.V);
-      float cosphi = fmaxf(dot(sp.N, h), 0.0f);
-      float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
-      V3 contrib = w * (inten * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
-      if (!nonzero(contrib)) continue;
-      GroupQ& G = soft ? GS : GH;
-      uint32_t gi = queue_push(G.count, G.cap, F.overflow);
-      if (gi == 0xFFFFFFFFu) continue;
+      RT_UTYPE(DLight)* L = lights + li;
+      int kind = L->kind;
+      if (kind == 1) continue;  // ambient is accumulated and never added  [uniform branch]
+      bool soft = false, lit = false;
+      V3 contrib = v3(0, 0, 0);
       float rx = 0, ry = 0;
+      if (kind == 3) soft = (L->size * P.light_size_scale) != 0.0f;
+      if (surface) {
+        V3 lightDir, inten = v3(L->intensity[0], L->intensity[1], L->intensity[2]);
+        if (kind == 2) {  // lights.h:45
+          lightDir = -v3(L->direction[0], L->direction[1], L->direction[2]);
+        } else {          // lights.cpp:62-71
+          V3 dl = v3(L->position[0], L->position[1], L->position[2]) - sp.P;
+          float dist = length(dl);
+          lightDir = normalized(dl);
+          if (L->attenuation != 0.0f) inten = inten / (dist * dist);
+        }
+        V3 h = normalized(lightDir + sp.V);
+        float cosphi = fmaxf(dot(sp.N, h), 0.0f);
+        float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
+        contrib = w * (inten * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
+        lit = nonzero(contrib);
+        if (lit && soft) {
+          float rl[4];
+          shade_draws(P, sp, 2 + (uint32_t)li, rl);
+          rx = rl[0]; ry = rl[1];
+        }
+      }
       if (soft) {
-        float rl[4];
-        shade_draws(P, sp, 2 + (uint32_t)li, rl);
-        rx = rl[0]; ry = rl[1];
-      }
-      G.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
-      G.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
-      G.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), 0.0f);
-    }
-
-    V3 local = emission;
-    if (P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
-      V3 wc = w * kd;
-      if (nonzero(wc)) {
-        if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
-        int hi = (sp.sample * P.mc_samples) % 1000;
-        float u1 = fmodf(S.halton[RT_HPHI + hi] + r1[2], 1.0f);
-        float u2 = fmodf(S.halton[RT_HTHETA + hi] + r1[3], 1.0f);
-        float r = sqrtf(u1);
-        float phi = two_pi_times(u2);
-        float x = r * cosf(phi), y = r * sinf(phi), zz = sqrtf(1.0f - u1);
-        V3 t, b;
-        orthonormals(sp.N, t, b);
-        V3 d = normalized((x * t) + (y * b) + (zz * sp.N));
-        uint32_t ci = queue_push(QN.count, QN.cap, F.overflow);
-        if (ci != 0xFFFFFFFFu) {
-          QN.q0[ci] = make_float4(sp.P.x, sp.P.y, sp.P.z, wc.x);
-          QN.q1[ci] = make_float4(d.x, d.y, d.z, wc.y);
-          QN.q2[ci] = make_float4(0.0f, 0.0f, 0.0f, wc.z);  // `dist` is unused by the sampler: no absorption
-          uint4 cm;
-          cm.x = slot; cm.y = pixel; cm.z = m.z; cm.w = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
-          QN.q3[ci] = cm;
+        uint32_t gi = seg_push(lit, GS.counts, oseg, GS.segcap, F.overflow);
+        if (gi != RT_NONE) {
+          GS.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
+          GS.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+          GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), 0.0f);
         }
-      }
-    } else if (P.photons) {  // materials.cpp:315-322
-      V3 wk = w * ((float)(1.0f / RT_PI_D) * kd);
-      if (nonzero(wk)) {
-        uint32_t gi = queue_push(GQ.count, GQ.cap, F.overflow);
-        if (gi != 0xFFFFFFFFu) {
-          GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));
-          GQ.b[gi] = make_float4(sp.N.x, sp.N.y, sp.N.z, __uint_as_float(secondary ? 1u : 0u));
-          GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
+      } else {
+        uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
+        if (gi != RT_NONE) {
+          GH.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
+          GH.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
         }
       }
     }
-    add_radiance(F, slot, w * local);
-  }
+    if (P.photons) {
+      uint32_t gi = seg_push(p_gather, GQ.counts, oseg, GQ.segcap, F.overflow);
+      if (gi != RT_NONE) {
+        GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));
+        GQ.b[gi] = make_float4(sp.N.x, sp.N.y, sp.N.z, __uint_as_float(secondary ? 1u : 0u));
+        GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
+      }
+    }
+  RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);
@@ -471,12 +596,13 @@ RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, G
 template <bool CNT>
 RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G) {
   RT_STACK_DECL
-  uint32_t n = *G.count;
-  if (n > G.cap) n = G.cap;
   Cnt<CNT> cnt;
   uint32_t rays = 0;
-  for (uint32_t g = RT_TID; g < n; g += RT_NTHREADS) {
-    float4 g0 = G.g0[g], g1 = G.g1[g];
+  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
+    if (!seg_valid) continue;
+    uint32_t g = seg_base_ + (uint32_t)seg_e;
+    float4 g1 = G.g1[g];
+    float4 g0 = G.g0[g];
     V3 Pp = v3(g0.x, g0.y, g0.z);
     const DLight& L = S.lights[__float_as_uint(g0.w)];
     V3 d;
@@ -491,7 +617,7 @@ RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G) {
     }
     rays++;
     if (!scene_any<CNT>(S, Pp, d, tmax, stk, stride, cnt)) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
-  }
+  RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
@@ -528,17 +654,15 @@ RT_DEV bool soft_sample_lit(const DScene& S, const PassP& P, float4 g0, float4 g
 template <bool CNT>
 RT_KERNEL(k_shadow_soft1, DScene S, PassP P, FrameBufs F, GroupQ G) {
   RT_STACK_DECL
-  uint32_t n = *G.count;
-  if (n > G.cap) n = G.cap;
   uint32_t n1 = (uint32_t)P.shadow_min;
-  unsigned long long total = (unsigned long long)n * n1;
   Cnt<CNT> cnt;
   uint32_t rays = 0;
-  for (unsigned long long r = RT_TID; r < total; r += RT_NTHREADS) {
-    uint32_t g = (uint32_t)(r / n1), j = (uint32_t)(r % n1);
+  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, n1)
+    if (!seg_valid) continue;
+    uint32_t g = seg_base_ + (uint32_t)(seg_e / n1), j = (uint32_t)(seg_e % n1);
     rays++;
     if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
-  }
+  RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
@@ -546,46 +670,49 @@ RT_KERNEL(k_shadow_soft1, DScene S, PassP P, FrameBufs F, GroupQ G) {
 }
 // early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues
 RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, uint32_t* list2, uint32_t* n2) {
-  uint32_t n = *G.count;
-  if (n > G.cap) n = G.cap;
-  for (uint32_t g = RT_TID; g < n; g += RT_NTHREADS) {
-    uint32_t lit = __float_as_uint(G.g2[g].z);
-    if (lit == (uint32_t)P.shadow_min || P.shadow_max <= P.shadow_min) {
-      float4 g1 = G.g1[g];
-      float vis = (float)lit / (float)P.shadow_min;
-      add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * vis);
-    } else {
-      list2[rt_atomic_add_u32(n2, 1u)] = g;
+  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
+    uint32_t g = seg_base_ + (uint32_t)seg_e;
+    bool more = false;
+    if (seg_valid) {
+      uint32_t lit = __float_as_uint(G.g2[g].z);
+      if (lit == (uint32_t)P.shadow_min || P.shadow_max <= P.shadow_min) {
+        float4 g1 = G.g1[g];
+        float vis = (float)lit / (float)P.shadow_min;
+        add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * vis);
+      } else {
+        more = true;
+      }
     }
-  }
+    uint32_t li = seg_push(more, n2, sw_.s, G.segcap, F.overflow);
+    if (li != RT_NONE) list2[li] = g;
+  RT_SEG_END
 }
 // phase 2: samples shadow_min .. shadow_max-1 of the groups that were not fully lit
 template <bool CNT>
 RT_KERNEL(k_shadow_soft2, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
   RT_STACK_DECL
-  uint32_t n = *n2;
   uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
-  unsigned long long total = (unsigned long long)n * nr;
   Cnt<CNT> cnt;
   uint32_t rays = 0;
-  for (unsigned long long r = RT_TID; r < total; r += RT_NTHREADS) {
-    uint32_t g = list2[(uint32_t)(r / nr)], j = (uint32_t)P.shadow_min + (uint32_t)(r % nr);
+  RT_SEG_BEGIN(n2, G.nseg, G.segcap, nr)
+    if (!seg_valid) continue;
+    uint32_t g = list2[seg_base_ + (uint32_t)(seg_e / nr)], j = (uint32_t)P.shadow_min + (uint32_t)(seg_e % nr);
     rays++;
     if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
-  }
+  RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
   }
 }
 RT_KERNEL(k_shadow_soft_final, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
-  uint32_t n = *n2;
-  for (uint32_t e = RT_TID; e < n; e += RT_NTHREADS) {
-    uint32_t g = list2[e];
+  RT_SEG_BEGIN(n2, G.nseg, G.segcap, 1u)
+    if (!seg_valid) continue;
+    uint32_t g = list2[seg_base_ + (uint32_t)seg_e];
     float4 g1 = G.g1[g];
     float vis = (float)__float_as_uint(G.g2[g].z) / (float)P.shadow_max;  // summedLight / numSamples, lights.cpp:66
     add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * vis);
-  }
+  RT_SEG_END
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate / resolve

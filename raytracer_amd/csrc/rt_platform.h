@@ -73,6 +73,19 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 }
 #endif
 
+// ---- wave-uniform read-only data ------------------------------------------------------------------
+// Scene tables that every lane of a wave reads at the same address (instance headers, transform chains, lights) are
+// read through the constant address space, so that hipcc emits scalar loads (s_load_*, one per wave, results in
+// SGPRs) instead of 64-lane vector loads whose latency sits in every ray's dependency chain.  The tables are
+// written only by the host before any kernel runs.
+#if !defined(RT_EMU) && !defined(RT_NO_UNIFORM)
+#define RT_UTYPE(T) const __attribute__((address_space(4))) T
+#define RT_UNIFORM_PTR(T, p) ((const __attribute__((address_space(4))) T*)(p))
+#else
+#define RT_UTYPE(T) const T
+#define RT_UNIFORM_PTR(T, p) ((const T*)(p))
+#endif
+
 // ---- atomics used by the kernels (plain adds in the single-threaded emulation) ------------------
 #ifndef RT_EMU
 RT_DEV uint32_t rt_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

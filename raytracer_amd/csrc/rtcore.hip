@@ -347,15 +347,13 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   photon_state_free(ctx->photons);
 
   // ---- nodes and instances
-  std::vector<DNode> nodes(sc->n_nodes);
   for (uint32_t i = 0; i < sc->n_nodes; i++) {
     const rt_node& n = sc->nodes[i];
     if (i == 0 ? n.parent != -1 : (n.parent < 0 || n.parent >= (int)i))
       return fail(ctx, RT_ERR_INVALID, "nodes must be in depth-first order with parent < index");
-    std::memcpy(nodes[i].itm, n.itm.m, sizeof nodes[i].itm);
-    std::memcpy(nodes[i].tm, n.tm.m, sizeof nodes[i].tm);
   }
   std::vector<DInstance> inst;
+  std::vector<float> xf;  // per instance: depth x { itm[12], tm[12] }, root level first
   for (uint32_t i = 0; i < sc->n_nodes; i++) {
     const rt_node& n = sc->nodes[i];
     if (n.prim_kind == RT_PRIM_NONE) continue;
@@ -371,7 +369,13 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     for (int k = (int)i; k >= 0 && d < 64; k = sc->nodes[k].parent) chain[d++] = k;
     if (d > RT_MAX_CHAIN) return fail(ctx, RT_ERR_UNSUPPORTED, "scene graph deeper than 8 levels");
     I.depth = d;
-    for (int k = 0; k < d; k++) I.chain[k] = chain[d - 1 - k];
+    I.parent_key = n.parent;
+    I.xf_off = (int32_t)xf.size();
+    for (int k = 0; k < d; k++) {
+      const rt_node& cn = sc->nodes[chain[d - 1 - k]];
+      xf.insert(xf.end(), cn.itm.m, cn.itm.m + 12);
+      xf.insert(xf.end(), cn.tm.m, cn.tm.m + 12);
+    }
     // padded world bounds (only mesh instances are culled with them)
     double lo[3], hi[3];
     if (n.prim_kind == RT_PRIM_MESH) {
@@ -386,7 +390,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     for (int c = 0; c < 8; c++) {
       double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
       for (int k = d - 1; k >= 0; k--) {
-        const float* t = sc->nodes[I.chain[k]].tm.m;
+        const float* t = sc->nodes[chain[d - 1 - k]].tm.m;
         double q[3];
         for (int r = 0; r < 3; r++) q[r] = (double)t[r] * p[0] + (double)t[3 + r] * p[1] + (double)t[6 + r] * p[2] + (double)t[9 + r];
         p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
@@ -498,7 +502,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   DScene& D = ctx->ds;
   std::memset(&D, 0, sizeof D);
   int rc;
-  if ((rc = upload(ctx, ctx->scene_mem, nodes, &D.nodes))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, xf, &D.xf))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, inst, &D.inst))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, bvh, &D.bvh))) return rc;
@@ -578,11 +582,16 @@ int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t
 // ================================================================================================ rendering
 namespace {
 
-enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_GH = 2, CNT_GS = 3, CNT_N2 = 4, CNT_GQ = 5, CNT_PER_LEVEL = 8 };
+// Device layout of the queue-length words: [level][kind][segment * RT_CSTRIDE]; then the overflow flag and the
+// active-pixel counter.  Level l's ray queue lengths live at (l, CNT_Q); its children are counted at (l + 1, CNT_Q).
+enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4, CNT_KINDS = 5 };
 constexpr int MAX_LEVELS = 8;
-constexpr int CNT_OVERFLOW = MAX_LEVELS * CNT_PER_LEVEL;
-constexpr int CNT_ACTIVE = CNT_OVERFLOW + 1;
-constexpr int CNT_TOTAL = CNT_OVERFLOW + 8;
+constexpr uint32_t NSEG = 64;
+constexpr size_t CNT_SLAB = (size_t)NSEG * RT_CSTRIDE;                       // words per (level, kind)
+constexpr size_t CNT_OVERFLOW = (size_t)(MAX_LEVELS + 1) * CNT_KINDS * CNT_SLAB;
+constexpr size_t CNT_ACTIVE = CNT_OVERFLOW + 1;
+constexpr size_t CNT_TOTAL = CNT_OVERFLOW + 8;
+inline size_t cnt_at(int level, int kind) { return ((size_t)level * CNT_KINDS + kind) * CNT_SLAB; }
 
 struct Timer {
   rt_context* ctx;
@@ -639,14 +648,20 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
   double worst = 1;
   for (int l = 1; l < fp.levels; l++) worst *= fp.branch;
-  size_t qcap = (size_t)std::min<double>((double)fp.budget * worst, 3.0e8);
+  // k_raygen deals 64-path tiles round-robin to NSEG segments; children stay in their parent's segment, so the
+  // worst-case segment length is the level-0 length times the worst-case fan-out.
+  size_t tiles = ((size_t)fp.budget + 63) / 64;
+  size_t seg0 = ((tiles + NSEG - 1) / NSEG) * 64;
+  size_t segcap = (size_t)std::min<double>((double)seg0 * worst, 3.0e8 / NSEG);
+  size_t qcap = segcap * NSEG;
   int rc;
   void* p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, CNT_TOTAL * sizeof(uint32_t), &p))) return rc;
   ctx->d_counts = (uint32_t*)p;
   for (int k = 0; k < 2; k++) {
     RayQ& q = ctx->Q[k];
-    q.cap = (uint32_t)qcap;
+    q.segcap = (uint32_t)segcap;
+    q.nseg = NSEG;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q0 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q1 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q2 = (float4*)p;
@@ -654,28 +669,33 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h0 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h1 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h2 = (float4*)p;
-    q.count = nullptr;
+    q.counts = nullptr;
   }
-  auto alloc_group = [&](GroupQ& g, size_t cap) {
-    g.cap = (uint32_t)std::max<size_t>(cap, 1);
+  auto alloc_group = [&](GroupQ& g, size_t per_entry) {
+    size_t sc = std::min<size_t>(segcap * std::max<size_t>(per_entry, 1), 0x7fffffffu / NSEG);
+    if (per_entry == 0) sc = 1;
+    g.segcap = (uint32_t)sc;
+    g.nseg = NSEG;
+    size_t cap = sc * NSEG;
     int r;
     void* pp;
-    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g0 = (float4*)pp;
-    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g1 = (float4*)pp;
-    if ((r = alloc_dev(ctx, ctx->frame_mem, (size_t)g.cap * 16, &pp))) return r; g.g2 = (float4*)pp;
-    g.count = nullptr;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g0 = (float4*)pp;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g1 = (float4*)pp;
+    if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp;
+    g.counts = nullptr;
     return (int)RT_OK;
   };
-  if ((rc = alloc_group(ctx->GH, std::min<size_t>(qcap * (size_t)fp.n_hard, 0x7fffffffu)))) return rc;
-  if ((rc = alloc_group(ctx->GS, std::min<size_t>(qcap * (size_t)fp.n_soft, 0x7fffffffu)))) return rc;
-  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.cap * 4, &p))) return rc;
+  if ((rc = alloc_group(ctx->GH, (size_t)fp.n_hard))) return rc;
+  if ((rc = alloc_group(ctx->GS, (size_t)fp.n_soft))) return rc;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.segcap * NSEG * 4, &p))) return rc;
   ctx->d_list2 = (uint32_t*)p;
-  size_t gcap = fp.photons ? qcap : 1;
-  ctx->GQ.cap = (uint32_t)gcap;
-  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.a = (float4*)p;
-  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
-  if ((rc = alloc_dev(ctx, ctx->frame_mem, gcap * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
-  ctx->GQ.count = nullptr;
+  size_t gsegcap = fp.photons ? segcap : 1;
+  ctx->GQ.segcap = (uint32_t)gsegcap;
+  ctx->GQ.nseg = NSEG;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.a = (float4*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
+  ctx->GQ.counts = nullptr;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 16, &p))) return rc;
   ctx->d_path_rad = (float4*)p;
   size_t npx = (size_t)fp.W * fp.H;
@@ -709,17 +729,13 @@ void build_pixel_list(const rt_render_params& P, int W, int H, std::vector<uint3
   }
 }
 
-struct PassCounts {
-  std::vector<uint32_t> v;
-};
-
 template <bool CNT>
 int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bool any_soft, bool any_hard, bool photons,
              const rt_render_params& RP) {
   HIP_TRY(hipMemsetAsync(ctx->d_counts, 0, CNT_TOTAL * sizeof(uint32_t), ctx->stream));
   uint32_t n0 = P.n_pix * (uint32_t)P.n_samples;
   RayQ Qc = ctx->Q[0], Qn = ctx->Q[1];
-  Qc.count = ctx->d_counts + 0 * CNT_PER_LEVEL + CNT_Q0;
+  Qc.counts = ctx->d_counts + cnt_at(0, CNT_Q);
   {
     Timer t(ctx, RT_K_RAYGEN);
     LAUNCH(k_raygen, n0, ctx->ds, P, F, Qc);
@@ -727,45 +743,46 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
   }
   double ub = n0;
   int branch = 2 + (P.mc_bounces > 0 ? 1 : 0);
+  const uint64_t qcap = (uint64_t)Qc.segcap * Qc.nseg;
   for (int lvl = 0; lvl < levels; lvl++) {
-    uint32_t* cbase = ctx->d_counts + lvl * CNT_PER_LEVEL;
-    uint32_t* cnext = ctx->d_counts + (lvl + 1) * CNT_PER_LEVEL;
-    Qn.count = (lvl + 1 < MAX_LEVELS) ? cnext + CNT_Q0 : cbase + CNT_Q1;
+    Qn.counts = ctx->d_counts + cnt_at(lvl + 1, CNT_Q);
     GroupQ GH = ctx->GH, GS = ctx->GS;
     GatherQ GQ = ctx->GQ;
-    GH.count = cbase + CNT_GH; GS.count = cbase + CNT_GS; GQ.count = cbase + CNT_GQ;
-    uint32_t* n2 = cbase + CNT_N2;
-    uint64_t ubn = (uint64_t)std::min<double>(ub, (double)Qc.cap);
+    GH.counts = ctx->d_counts + cnt_at(lvl, CNT_GH);
+    GS.counts = ctx->d_counts + cnt_at(lvl, CNT_GS);
+    GQ.counts = ctx->d_counts + cnt_at(lvl, CNT_GQ);
+    uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
+    uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
     {
       Timer t(ctx, RT_K_TRACE_CLOSEST);
       LAUNCH(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, lvl);
-      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_Q0));
+      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
     }
     {
       Timer t(ctx, RT_K_SHADE);
       LAUNCH(k_shade<CNT>, ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_Q0));
+      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
     }
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
-      LAUNCH(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, GH.cap), ctx->ds, P, F, GH);
-      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GH));
+      LAUNCH(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg), ctx->ds, P, F, GH);
+      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
     }
     if (any_soft) {
       Timer t(ctx, RT_K_SHADOW);
-      uint64_t gs_ub = std::min<uint64_t>(ubn * 4, GS.cap);
+      uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
       LAUNCH(k_shadow_soft1<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS);
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
         LAUNCH(k_shadow_soft2<CNT>, gs_ub * (uint64_t)(P.shadow_max - P.shadow_min), ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
-      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GS));
+      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
     }
     if (photons) {
       Timer t(ctx, RT_K_PHOTON_GATHER);
       photon_gather_queue(ctx->photons, ctx->stream, ctx->max_blocks, GQ, F, RP, ubn);
-      t.stop((uint64_t)(lvl * CNT_PER_LEVEL + CNT_GQ));
+      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GQ));
     }
     std::swap(Qc, Qn);
     ub *= branch;
@@ -876,13 +893,22 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   F.overflow = ctx->d_counts + CNT_OVERFLOW;
   F.counters = ctx->d_counters;
 
-  std::vector<uint32_t> counts(CNT_TOTAL);
+  std::vector<uint32_t> raw(CNT_TOTAL), counts((MAX_LEVELS + 1) * CNT_KINDS);
   auto finish_pass = [&](uint64_t paths) -> int {
-    HIP_TRY(hipMemcpyAsync(counts.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // queue lengths are only needed for the profile's item counts; the overflow flag always
+    size_t first = ctx->profile_on ? 0 : CNT_OVERFLOW;
+    HIP_TRY(hipMemcpyAsync(raw.data() + first, ctx->d_counts + first, (CNT_TOTAL - first) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
-    collect_profile(ctx, counts);
-    if (counts[CNT_OVERFLOW]) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow");
+    if (ctx->profile_on) {
+      for (size_t s = 0; s < counts.size(); s++) {
+        uint64_t sum = 0;
+        for (uint32_t g = 0; g < NSEG; g++) sum += raw[s * CNT_SLAB + (size_t)g * RT_CSTRIDE];
+        counts[s] = (uint32_t)std::min<uint64_t>(sum, 0xffffffffu);
+      }
+      collect_profile(ctx, counts);
+    }
+    if (raw[CNT_OVERFLOW]) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow");
     if (ctx->counters_on) ctx->host_paths += paths;
     return RT_OK;
   };
