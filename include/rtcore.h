@@ -273,6 +273,10 @@ int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_ac
 int rt_photons_build(rt_context* ctx, const rt_render_params* params);
 /* GetPhotonMap / GetCausticsMap (raytracer.h:41-42): which = 0 global, 1 caustics. */
 int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n);
+/* Replaces one map by caller-supplied photons in insertion order, powers already scaled (what a host that traced
+ * its own photons through PhotonMap::AddPhoton + ScalePhotonPowers would hold, photonmap.h:82,158-172), then
+ * PrepareForIrradianceEstimation (photonmap.h:176-198). */
+int rt_photons_set(rt_context* ctx, int which, const rt_photon* photons, int32_t n);
 /* Batched PhotonMap::EstimateIrradiance<k> (photonmap.h:98-99,268-309). Host pointers, 3 floats each. */
 int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N, size_t n,
                      float radius, float ellipticity, int k, float* irradiance);

@@ -209,6 +209,11 @@ class Renderer:
     def GetCausticsMap(self):
         return self._photons(1)
 
+    def SetPhotonMap(self, which, photons):
+        """Caller-supplied photons (insertion order, powers scaled), then PrepareForIrradianceEstimation."""
+        photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+        self._check(self._lib.rt_photons_set(self._ctx, which, photons.ctypes.data, len(photons)), "rt_photons_set")
+
     def EstimateIrradiance(self, which, P, N, radius=3.0, ellipticity=1.0, k=128):
         P = np.ascontiguousarray(P, dtype=np.float32)
         N = np.ascontiguousarray(N, dtype=np.float32)

@@ -190,7 +190,7 @@ def load_host():
 CORE_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_commit", "rt_trace_closest", "rt_trace_any",
     "rt_render", "rt_render_begin", "rt_render_poll", "rt_render_wait", "rt_render_accumulate", "rt_resolve",
-    "rt_photons_build", "rt_photons_download", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
+    "rt_photons_build", "rt_photons_download", "rt_photons_set", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
     "rt_counters_reset", "rt_counters_get", "rt_profile_enable", "rt_profile_reset", "rt_profile_get",
     "rt_render_params_default",
 ]
@@ -255,6 +255,7 @@ def bind_core(lib):
     lib.rt_resolve.argtypes = [vp, C.POINTER(rt_render_params), vp, C.POINTER(rt_framebuffer)]
     lib.rt_photons_build.argtypes = [vp, C.POINTER(rt_render_params)]
     lib.rt_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rt_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.rt_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
     lib.rt_denoise.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.rt_counters_enable.argtypes = [vp, C.c_int]

@@ -36,6 +36,7 @@
 #define RT_BLOCK 1
 struct float4 { float x, y, z, w; };
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }

@@ -247,21 +247,6 @@ int fail(rt_context* ctx, int code, const std::string& msg) {
   return code;
 }
 
-// ---- photon pass entry points (filled in by the photon-map milestone)
-int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params& RP) {
-  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore (set params.photons = 0)");
-}
-int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
-  *n = 0;
-  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore");
-}
-int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius,
-                      float ellipticity, int k, float* irradiance) {
-  return fail(ctx, RT_ERR_UNSUPPORTED, "photon maps are not built into this revision of librtcore");
-}
-void photon_gather_queue(PhotonState& ps, hipStream_t stream, int max_blocks, const GatherQ& GQ, const FrameBufs& F,
-                         const rt_render_params& RP, uint64_t upper) {}
-
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -632,6 +617,284 @@ void collect_profile(rt_context* ctx, const std::vector<uint32_t>& counts) {
   ctx->ev_used.clear();
 }
 
+// ---- photon pass (RayTracer::GeneratePhotons, RayTracer.cpp:262-294)
+
+// PhotonMap::BalanceSegment (photonmap.h:202-264) on the host, as the reference does it: the left-balanced kd-tree in
+// heap order.  `ph` is 1-based (slot 0 unused), `bal` receives the tree.
+void photon_balance_segment(std::vector<rt_photon>& ph, std::vector<rt_photon>& bal, const float* bmin, const float* bmax,
+                            int index, int start, int end) {
+  int median = 1;
+  while ((4 * median) <= (end - start + 1)) median += median;
+  if ((3 * median) <= (end - start + 1)) {
+    median += median;
+    median += start - 1;
+  } else {
+    median = end - median + 1;
+  }
+  int axis = 2;
+  float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
+  if (dx > dy) {
+    if (dx > dz) axis = 0;
+  } else if (dy > dz) {
+    axis = 1;
+  }
+  int left = start, right = end;
+  while (right > left) {
+    const float v = ph[right].position[axis];
+    int i = left - 1, j = right;
+    while (ph[++i].position[axis] < v) {}
+    while (ph[--j].position[axis] > v && j > left) {}
+    while (i < j) {
+      std::swap(ph[i], ph[j]);
+      while (ph[++i].position[axis] < v) {}
+      while (ph[--j].position[axis] > v && j > left) {}
+    }
+    std::swap(ph[i], ph[right]);
+    if (i >= median) right = i - 1;
+    if (i <= median) left = i + 1;
+  }
+  bal[index] = ph[median];
+  bal[index].plane = (uint8_t)((bal[index].plane & 0x8) | (axis & 0x3));
+  if (median > start) {
+    if (start < median - 1) {
+      float tmax[3] = {bmax[0], bmax[1], bmax[2]};
+      tmax[axis] = bal[index].position[axis];
+      photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1);
+    } else {
+      bal[2 * index] = ph[start];
+    }
+  }
+  if (median < end) {
+    if (median + 1 < end) {
+      float tmin[3] = {bmin[0], bmin[1], bmin[2]};
+      tmin[axis] = bal[index].position[axis];
+      photon_balance_segment(ph, bal, tmin, bmax, 2 * index + 1, median + 1, end);
+    } else {
+      bal[2 * index + 1] = ph[end];
+    }
+  }
+}
+
+// PhotonMap::PrepareForIrradianceEstimation (photonmap.h:176-198).  raw = photons in insertion order.
+void photon_balance(const std::vector<rt_photon>& raw, std::vector<rt_photon>& bal) {
+  int stored = (int)raw.size();
+  bal.assign((size_t)stored + 2, rt_photon{});
+  if (stored == 0) return;
+  std::vector<rt_photon> ph((size_t)stored + 1);
+  std::memset(&ph[0], 0, sizeof(rt_photon));  // photons[0] is a value-initialised slot: the origin joins the box
+  std::copy(raw.begin(), raw.end(), ph.begin() + 1);
+  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+  for (int i = 1; i <= stored; i++)
+    for (int a = 0; a < 3; a++) {
+      if (bmin[a] > ph[i].position[a]) bmin[a] = ph[i].position[a];
+      if (bmax[a] < ph[i].position[a]) bmax[a] = ph[i].position[a];
+    }
+  photon_balance_segment(ph, bal, bmin, bmax, 1, 1, stored);
+}
+
+int photon_upload_map(PhotonState& ps, rt_context* ctx, int which, const std::vector<rt_photon>& raw) {
+  std::vector<rt_photon> bal;
+  photon_balance(raw, bal);
+  if (ps.d_map[which]) { (void)hipFree(ps.d_map[which]); ps.d_map[which] = nullptr; }
+  HIP_TRY(hipMalloc(&ps.d_map[which], bal.size() * sizeof(rt_photon)));
+  HIP_TRY(hipMemcpy(ps.d_map[which], bal.data(), bal.size() * sizeof(rt_photon), hipMemcpyHostToDevice));
+  ps.count[which] = (int32_t)raw.size();
+  ps.raw[which] = raw;
+  return RT_OK;
+}
+
+DPhotonMap photon_dmap(const PhotonState& ps, int which) {
+  DPhotonMap m;
+  m.ph = (const float4*)ps.d_map[which];
+  m.stored = ps.count[which];
+  m.half = ps.count[which] / 2 - 1;
+  return m;
+}
+
+int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params& RP) {
+  static_assert(sizeof(rt_photon) == 32, "rt_photon must be PhotonData's 32 bytes");
+  if (RP.n_photons <= 0 || RP.n_photons > (1 << 26)) return fail(ctx, RT_ERR_INVALID, "n_photons out of range");
+  if (RP.photon_k <= 0 || RP.photon_k > RT_PHOTON_MAX_K) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_k must be in 1..256");
+  long long limit = RP.photon_emit_limit > 0 ? RP.photon_emit_limit : 20ll * RP.n_photons;
+  int max_b = RP.photon_max_bounces > 0 ? RP.photon_max_bounces : 64;
+  uint32_t key[8] = {RP.seed_lo, RP.seed_hi, (uint32_t)RP.n_photons, (uint32_t)limit, (uint32_t)max_b, 1u, 0u, 0u};
+  if (ps.built && !std::memcmp(key, ps.key, sizeof key)) return RT_OK;
+  ps.built = false;
+  const uint32_t n = (uint32_t)RP.n_photons;
+  std::vector<int32_t> plights;
+  for (size_t l = 0; l < ctx->lights.size(); l++)
+    if (ctx->lights[l].kind == RT_LIGHT_POINT) plights.push_back((int32_t)l);  // IsPhotonSource, lights.h:63
+
+  std::vector<rt_photon> kept[2];
+  uint32_t emitted = 0;
+  if (!plights.empty()) {
+    uint32_t batch = 1u << 16;
+    std::vector<DevMem> tmp;
+    int rc = RT_OK;
+    struct Cleanup { std::vector<DevMem>& t; ~Cleanup() { free_pool(t); } } cleanup{tmp};
+    void *d_rec[2], *d_key[2], *d_cnt, *d_pl;
+    const uint32_t per_path = 16;  // deposit records a batch may add per path before the batch is retried smaller
+    uint32_t cap = batch * per_path;
+    for (int w = 0; w < 2; w++) {
+      if ((rc = alloc_dev(ctx, tmp, (size_t)cap * 32, &d_rec[w]))) return rc;
+      if ((rc = alloc_dev(ctx, tmp, (size_t)cap * 8, &d_key[w]))) return rc;
+    }
+    if ((rc = alloc_dev(ctx, tmp, 16, &d_cnt))) return rc;
+    if ((rc = alloc_dev(ctx, tmp, plights.size() * 4, &d_pl))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_pl, plights.data(), plights.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<rt_photon> h_rec;
+    std::vector<uint64_t> h_key;
+    std::vector<uint32_t> order;
+    while ((kept[0].size() < n || kept[1].size() < n) && (long long)emitted < limit) {
+      uint32_t count = (uint32_t)std::min<long long>(batch, limit - emitted);
+      PhotonTraceP PP;
+      PP.seed_lo = RP.seed_lo; PP.seed_hi = RP.seed_hi;
+      PP.first = emitted; PP.count = count;
+      PP.max_bounces = max_b;
+      PP.n_plights = (int32_t)plights.size();
+      PP.accept[0] = kept[0].size() < n; PP.accept[1] = kept[1].size() < n;
+      PP.cap = cap;
+      PhotonOut O;
+      for (int w = 0; w < 2; w++) { O.rec[w] = (float4*)d_rec[w]; O.key[w] = (uint2*)d_key[w]; }
+      O.count = (uint32_t*)d_cnt;
+      O.overflow = (uint32_t*)d_cnt + 2;
+      O.plights = (const int32_t*)d_pl;
+      O.counters = ctx->d_counters;
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
+      {
+        Timer t(ctx, RT_K_PHOTON_TRACE);
+        if (ctx->counters_on) LAUNCH(k_photon_trace<true>, count, ctx->ds, PP, O);
+        else LAUNCH(k_photon_trace<false>, count, ctx->ds, PP, O);
+        t.stop((1ull << 32) + count);
+      }
+      uint32_t h_cnt[4];
+      HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipGetLastError());
+      if (h_cnt[2]) {  // more deposits than the record buffers hold: redo these paths in smaller batches
+        if (batch <= 1024) return fail(ctx, RT_ERR_OVERFLOW, "photon deposit buffer overflow");
+        batch /= 4;
+        continue;
+      }
+      for (int w = 0; w < 2; w++) {
+        uint32_t m = h_cnt[w];
+        if (!m || kept[w].size() >= n) continue;
+        h_rec.resize(m);
+        h_key.resize(m);
+        HIP_TRY(hipMemcpy(h_rec.data(), d_rec[w], (size_t)m * 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_key.data(), d_key[w], (size_t)m * 8, hipMemcpyDeviceToHost));
+        // the sequential emitter stores deposits in (path, bounce) order and stops storing when the map is full
+        order.resize(m);
+        for (uint32_t i = 0; i < m; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+          uint64_t ka = (h_key[a] << 32) | (h_key[a] >> 32), kb = (h_key[b] << 32) | (h_key[b] >> 32);  // uint2 {path, bounce}
+          return ka < kb;
+        });
+        for (uint32_t i = 0; i < m && kept[w].size() < n; i++) kept[w].push_back(h_rec[order[i]]);
+      }
+      emitted += count;
+    }
+    if (ctx->profile_on) {
+      std::vector<uint32_t> none;
+      collect_profile(ctx, none);
+    }
+  }
+  // RayTracer.cpp:290,292: powers scaled by 1 / numPhotons (the map's capacity)
+  const float scale = 1.0f / (float)RP.n_photons;
+  for (int w = 0; w < 2; w++)
+    for (auto& p : kept[w]) p.power *= scale;
+  int rc;
+  if ((rc = photon_upload_map(ps, ctx, 0, kept[0]))) return rc;
+  if ((rc = photon_upload_map(ps, ctx, 1, kept[1]))) return rc;
+  ps.emitted = emitted;
+  std::memcpy(ps.key, key, sizeof key);
+  ps.built = true;
+  return RT_OK;
+}
+
+int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
+  *n = 0;
+  if (which < 0 || which > 1) return fail(ctx, RT_ERR_INVALID, "which must be 0 (global) or 1 (caustics)");
+  if (!ps.built) return fail(ctx, RT_ERR_NOSCENE, "photon maps have not been built (rt_photons_build)");
+  int32_t m = (int32_t)ps.raw[which].size();
+  *n = m;
+  if (out) {
+    if (capacity < m) return fail(ctx, RT_ERR_INVALID, "photon buffer too small");
+    std::memcpy(out, ps.raw[which].data(), (size_t)m * sizeof(rt_photon));
+  }
+  return RT_OK;
+}
+
+int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* photons, int32_t n) {
+  if (which < 0 || which > 1 || n < 0 || (n && !photons)) return fail(ctx, RT_ERR_INVALID, "bad photon array");
+  std::vector<rt_photon> raw(photons, photons + n);
+  int rc = photon_upload_map(ps, ctx, which, raw);
+  if (rc) return rc;
+  if (!ps.built) {
+    if (!ps.d_map[1 - which]) {
+      std::vector<rt_photon> empty;
+      if ((rc = photon_upload_map(ps, ctx, 1 - which, empty))) return rc;
+    }
+    std::memset(ps.key, 0xff, sizeof ps.key);  // caller-supplied maps: never mistaken for a built parameter set
+    ps.built = true;
+  }
+  return RT_OK;
+}
+
+#ifndef RT_EMU
+#define LAUNCH_GATHER(kern, n_items, k_, ...)                                                              \
+  do {                                                                                                     \
+    unsigned long long nb_ = ((unsigned long long)(n_items) + RT_GATHER_BLOCK - 1) / RT_GATHER_BLOCK;      \
+    if (nb_ < 1) nb_ = 1;                                                                                  \
+    if (nb_ > (unsigned long long)ctx->max_blocks * 4) nb_ = (unsigned long long)ctx->max_blocks * 4;      \
+    size_t lds_ = photon_heap_bytes(k_);                                                                   \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);   \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_GATHER_BLOCK), lds_, ctx->stream, __VA_ARGS__);  \
+  } while (0)
+#else
+#define LAUNCH_GATHER(kern, n_items, k_, ...) kern(__VA_ARGS__)
+#endif
+
+int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius,
+                      float ellipticity, int k, float* irradiance) {
+  if (which < 0 || which > 1) return fail(ctx, RT_ERR_INVALID, "which must be 0 (global) or 1 (caustics)");
+  if (!ps.built) return fail(ctx, RT_ERR_NOSCENE, "photon maps have not been built (rt_photons_build)");
+  if (k <= 0 || k > RT_PHOTON_MAX_K) return fail(ctx, RT_ERR_UNSUPPORTED, "k must be in 1..256");
+  if (n == 0) return RT_OK;
+  if (n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "too many queries");
+  std::vector<DevMem> tmp;
+  void *d_p, *d_n, *d_o;
+  int rc;
+  if ((rc = alloc_dev(ctx, tmp, n * 12, &d_p)) || (rc = alloc_dev(ctx, tmp, n * 12, &d_n)) || (rc = alloc_dev(ctx, tmp, n * 12, &d_o))) {
+    free_pool(tmp);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_p, P, n * 12, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_n, N, n * 12, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    LAUNCH_GATHER(k_api_photon_gather, n, k, photon_dmap(ps, which), (const float*)d_p, (const float*)d_n, (uint32_t)n, radius,
+                  ellipticity, k, (float*)d_o);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(irradiance, d_o, n * 12, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(tmp);
+  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+template <bool CNT>
+void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F, const rt_render_params& RP, uint64_t upper) {
+  GatherP G;
+  G.map[0] = photon_dmap(ctx->photons, 0);
+  G.map[1] = photon_dmap(ctx->photons, 1);
+  G.radius = RP.photon_radius;
+  G.ellipticity[0] = RP.ellipticity_global;
+  G.ellipticity[1] = RP.ellipticity_caustic;
+  G.k = RP.photon_k;
+  LAUNCH_GATHER(k_photon_gather<CNT>, upper, RP.photon_k, G, F, GQ);
+}
+
 struct FramePlan {
   int W, H;
   int levels;         // number of shading levels (max bounce depth + 1)
@@ -781,7 +1044,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (photons) {
       Timer t(ctx, RT_K_PHOTON_GATHER);
-      photon_gather_queue(ctx->photons, ctx->stream, ctx->max_blocks, GQ, F, RP, ubn);
+      photon_gather_queue<CNT>(ctx, GQ, F, RP, ubn);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GQ));
     }
     std::swap(Qc, Qn);
@@ -1093,6 +1356,13 @@ int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capa
   if (!ctx || !n) return RT_ERR_INVALID;
   HIP_TRY(hipSetDevice(ctx->device));
   return photon_download(ctx->photons, ctx, which, out, capacity, n);
+}
+
+int rt_photons_set(rt_context* ctx, int which, const rt_photon* photons, int32_t n) {
+  if (!ctx) return RT_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return photon_set(ctx->photons, ctx, which, photons, n);
 }
 
 int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius, float ellipticity,

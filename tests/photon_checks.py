@@ -1,0 +1,121 @@
+"""Photon-map parity checks shared by the CPU-side emulation tests and the GPU tests (reference RayTracer.cpp:262-334,
+photonmap.h, materials.cpp:315-390).  `r` is a Renderer (HIP library on the GPU box, host emulation on CPU)."""
+import numpy as np
+
+import oracle_ffi
+from common import params, psnr8
+from raytracer_amd import PHOTON_DTYPE
+
+
+def photon_params(n_photons, w=64, h=36, spp=1, bounces=2, k=32, emit_limit=0):
+    p = params(w, h, spp=spp, jitter=1, bounces=bounces, photons=1)
+    p.n_photons = n_photons
+    p.photon_k = k
+    p.photon_emit_limit = emit_limit
+    return p
+
+
+def synthetic_photons(n, seed, flat=False):
+    """n photons uniformly in a box (or on the plane z = 0: exact coordinate ties for the kd-tree balance)."""
+    rng = np.random.default_rng(seed)
+    ph = np.zeros(n, dtype=PHOTON_DTYPE)
+    pos = (rng.random((n, 3), dtype=np.float32) * np.float32(10.0) - np.float32(5.0)).astype(np.float32)
+    if flat:
+        pos[:, 2] = 0.0
+        pos[:, 0] = np.round(pos[:, 0] * 4) / 4   # repeated x values as well
+    ph["position"] = pos
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 2] = -np.abs(d[:, 2]) - 0.1
+    ph["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    ph["power"] = (0.5 + rng.random(n, dtype=np.float32)) / np.float32(n)
+    ph["color"] = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    return ph
+
+
+def queries(n, seed, flat=False):
+    rng = np.random.default_rng(seed)
+    P = (rng.random((n, 3), dtype=np.float32) * np.float32(10.0) - np.float32(5.0)).astype(np.float32)
+    if flat:
+        P[:, 2] = (rng.random(n, dtype=np.float32) * np.float32(0.2) - np.float32(0.1))
+    N = np.zeros((n, 3), np.float32)
+    N[:, 2] = 1.0
+    tilt = rng.normal(scale=0.2, size=(n, 3)).astype(np.float32)
+    N = N + tilt
+    N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+    return P, N
+
+
+def check_gather_matches_kdtree_walk(r, scene, n_photons=5000, n_queries=400):
+    """rt_photon_gather vs the oracle's restatement of PhotonMap::EstimateIrradiance on the same caller-supplied
+    photons: the same kd-tree, the same walk, the same heap => the same photon set and sum order.  Bit-exact."""
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    for which, flat, k, radius, ell in [(0, False, 32, 1.5, 1.0), (1, False, 128, 3.0, 0.25), (0, True, 16, 2.0, 1.0),
+                                         (1, True, 64, 50.0, 0.5), (0, False, 256, 100.0, 1.0)]:
+        ph = synthetic_photons(n_photons, seed=11 + which, flat=flat)
+        r.SetPhotonMap(which, ph)
+        orc.photons_set(which, ph)
+        P, N = queries(n_queries, seed=5, flat=flat)
+        g = r.EstimateIrradiance(which, P, N, radius=radius, ellipticity=ell, k=k)
+        c = orc.photon_gather(which, P, N, radius=radius, ellipticity=ell, k=k)
+        assert (c > 0).any(), "degenerate check: no query found a photon"
+        assert np.array_equal(g, c), f"gather differs (which={which}, flat={flat}, k={k}): max {np.abs(g - c).max()}"
+    # edge cases: empty map, one photon, fewer photons than k
+    for n in (0, 1, 3):
+        ph = synthetic_photons(n, seed=3)
+        r.SetPhotonMap(0, ph)
+        orc.photons_set(0, ph)
+        P, N = queries(50, seed=9)
+        g = r.EstimateIrradiance(0, P, N, radius=100.0, ellipticity=1.0, k=8)
+        c = orc.photon_gather(0, P, N, radius=100.0, ellipticity=1.0, k=8)
+        assert np.array_equal(g, c), f"gather differs on a {n}-photon map"
+
+
+def check_photon_maps_match_sequential_emitter(r, scene, n_photons=2000, emit_limit=0, exact=True):
+    """rt_photons_build vs the oracle's sequential GeneratePhotons at the same Philox seed: same number of photons in
+    both maps, in the same order; positions / directions / powers agree (bit-exact for the emulation build; on the GPU
+    a path may diverge where a transcendental ulp flips a roulette or hit decision, bounded below)."""
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p = photon_params(n_photons, emit_limit=emit_limit)
+    r.BuildPhotonMaps(p)
+    orc.photons_build(p)
+    out = {}
+    for which, getter in ((0, r.GetPhotonMap), (1, r.GetCausticsMap)):
+        g, c = getter(), orc.photons(which)
+        assert len(g) == len(c), f"map {which}: {len(g)} photons vs {len(c)}"
+        out[which] = len(g)
+        if len(g) == 0:
+            continue
+        dpos = np.abs(g["position"] - c["position"]).max(axis=1)
+        ok = dpos <= 1e-3
+        if exact:
+            assert ok.all(), f"map {which}: {np.count_nonzero(~ok)} photons differ in position"
+        else:
+            assert ok.mean() >= 0.98, f"map {which}: only {ok.mean():.3f} of the photons match"
+        assert np.abs(g["dir"][ok] - c["dir"][ok]).max() <= 1e-3
+        # (powers can be negative: mult = ks * dot(newDir, N) is not clamped, materials.cpp:372)
+        rel = np.abs(g["power"][ok] - c["power"][ok]) / np.maximum(np.abs(c["power"][ok]), 1e-12)
+        assert rel.max() <= 2e-3
+        assert np.abs(g["color"][ok].astype(int) - c["color"][ok].astype(int)).max() <= 1
+    return out
+
+
+def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=45.0, tol=2e-3):
+    """Whole frame with the photon term on (materials.cpp:315-322): global map on primary hits, caustics map on
+    secondary hits.  The oracle gathers from the DEVICE's photons so that the comparison isolates gather + shading."""
+    r.LoadScene(scene)
+    p = photon_params(n_photons, w=w, h=h, spp=spp)
+    g = r.Render(p)
+    orc = oracle_ffi.OracleScene(scene)
+    orc.photons_set(0, r.GetPhotonMap())
+    orc.photons_set(1, r.GetCausticsMap())
+    c, cnt = orc.render(p, want_counters=True)
+    assert cnt["gathers"] > 0
+    q = photon_params(n_photons, w=w, h=h, spp=spp)
+    q.photons = 0
+    base = orc.render(q)
+    assert np.abs(c.radiance[..., :3] - base.radiance[..., :3]).max() > 1e-2, "photon term contributes nothing"
+    assert psnr8(g.img, c.img) >= psnr_min
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean() <= tol
+    return g, c

@@ -1,0 +1,47 @@
+"""CPU-side check of the photon pass and gather logic (host emulation build vs the oracle); see photon_checks.py."""
+import pytest
+
+import emu_ffi
+import photon_checks as pc
+from conftest import scene_path
+from raytracer_amd import Scene
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_ffi.EmuRenderer()
+
+
+def test_gather_matches_kdtree_walk(emu):
+    pc.check_gather_matches_kdtree_walk(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=3000, n_queries=200)
+
+
+def test_photon_maps_match_sequential_emitter(emu):
+    n = pc.check_photon_maps_match_sequential_emitter(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=1500)
+    assert n[0] == 1500 and n[1] == 1500
+
+
+def test_emit_limit_leaves_caustics_map_partly_filled(emu):
+    """The reference loops forever when a map cannot fill (RayTracer.cpp:277); photon_emit_limit bounds it."""
+    n = pc.check_photon_maps_match_sequential_emitter(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=1500,
+                                                      emit_limit=2500)
+    assert n[0] == 1500 and 0 < n[1] < 1500
+
+
+DIFFUSE_ONLY = """<xml><scene>
+  <object type="plane" name="floor" material="m"> <scale value="20"/> </object>
+  <object type="sphere" name="ball" material="m"> <scale value="2"/> <translate z="2"/> </object>
+  <material type="blinn" name="m"> <diffuse r="0.8" g="0.6" b="0.4"/> <specular value="0"/> </material>
+  <light type="point"> <intensity value="50"/> <position x="1" y="-2" z="9"/> <size value="0.5"/> </light>
+</scene><camera> <position x="0" y="-20" z="6"/> <target x="0" y="0" z="2"/> <up x="0" y="0" z="1"/> <fov value="40"/>
+  <width value="64"/> <height value="48"/> </camera></xml>"""
+
+
+def test_no_specular_path_scene_terminates(emu):
+    """No specular -> diffuse path exists, so the caustics map stays empty; the reference would never return."""
+    n = pc.check_photon_maps_match_sequential_emitter(emu, Scene.from_string(DIFFUSE_ONLY), n_photons=300)
+    assert n[0] == 300 and n[1] == 0
+
+
+def test_photon_render(emu):
+    pc.check_photon_render(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=2000, w=48, h=27, spp=2, tol=1e-4)

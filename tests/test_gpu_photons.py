@@ -1,0 +1,38 @@
+"""GPU parity of the photon pass (k_photon_trace) and the irradiance gather (k_photon_gather) through the C-ABI."""
+import numpy as np
+import pytest
+
+import photon_checks as pc
+from conftest import scene_path
+from raytracer_amd import Scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_bit_exact(gpu_renderer):
+    pc.check_gather_matches_kdtree_walk(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000,
+                                        n_queries=4096)
+
+
+def test_photon_maps_match_sequential_emitter(gpu_renderer):
+    n = pc.check_photon_maps_match_sequential_emitter(gpu_renderer, Scene.load(scene_path("cornell_box.xml")),
+                                                      n_photons=20000, exact=False)
+    assert n[0] == 20000 and n[1] == 20000
+
+
+def test_photon_maps_reference_size(gpu_renderer):
+    """numPhotons = 100000 per map (raytracer.h:23): both maps fill, the build is reproducible run to run."""
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    gpu_renderer.LoadScene(scene)
+    p = pc.photon_params(100000)
+    gpu_renderer.BuildPhotonMaps(p)
+    a0, a1 = gpu_renderer.GetPhotonMap(), gpu_renderer.GetCausticsMap()
+    gpu_renderer.BuildPhotonMaps(p)
+    b0, b1 = gpu_renderer.GetPhotonMap(), gpu_renderer.GetCausticsMap()
+    assert len(a0) == 100000 and len(a1) == 100000
+    assert a0.tobytes() == b0.tobytes() and a1.tobytes() == b1.tobytes()
+
+
+def test_photon_render(gpu_renderer):
+    pc.check_photon_render(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000, w=240, h=135, spp=4,
+                           psnr_min=40.0)
