@@ -47,6 +47,10 @@ int orc_photons_set(orc_scene* s, int which, const rt_photon* photons, int32_t n
 void orc_photon_gather(const orc_scene* s, int which, const float* P, const float* N, size_t n, float radius,
                        float ellipticity, int k, float* irradiance);
 
+/* This build's own denoise filter restated on the CPU (the reference's is Intel OIDN: parity unpinned).
+ * rgb_in/out, albedo, normal: W*H*3 floats; albedo/normal may be NULL. */
+void orc_denoise(const float* rgb_in, float* rgb_out, int width, int height, const float* albedo, const float* normal);
+
 /* rng.h restated */
 void orc_pcg32_seq(uint64_t sequence, uint64_t seed, int use_seed, int n, uint32_t* out_u32, float* out_f32);
 float orc_halton(int index, int base);

@@ -4,6 +4,7 @@
 // single-threaded host emulation used by CPU-side unit tests only; see rt_platform.h.)
 #include "rt_kernels.h"
 #include "rt_photon.h"
+#include "rt_denoise.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1376,7 +1377,54 @@ int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N,
 int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t width, int32_t height, const float* albedo,
                const float* normal) {
   if (!ctx) return RT_ERR_INVALID;
-  return fail(ctx, RT_ERR_UNSUPPORTED, "denoise filter not built yet");
+  if (!rgb_in || !rgb_out || width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+    return fail(ctx, RT_ERR_INVALID, "bad denoise arguments");
+  if (ctx->worker.joinable()) ctx->worker.join();
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)width * height;
+  std::vector<DevMem> tmp;
+  struct Cleanup { std::vector<DevMem>& t; ~Cleanup() { free_pool(t); } } cleanup{tmp};
+  void *d_rgb, *d_a = nullptr, *d_b = nullptr, *d_alb = nullptr, *d_nrm = nullptr;
+  int rc;
+  if ((rc = alloc_dev(ctx, tmp, n * 12, &d_rgb)) || (rc = alloc_dev(ctx, tmp, n * 16, &d_a)) || (rc = alloc_dev(ctx, tmp, n * 16, &d_b))) return rc;
+  auto stage = [&](const float* host, void** d_img) -> int {  // host rgb -> device rgba
+    int r = alloc_dev(ctx, tmp, n * 16, d_img);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(d_rgb, host, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(k_dn_pack, n, (const float*)d_rgb, (float4*)*d_img, (uint32_t)n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+  };
+  if (albedo && (rc = stage(albedo, &d_alb))) return rc;
+  if (normal && (rc = stage(normal, &d_nrm))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_rgb, rgb_in, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  LAUNCH(k_dn_pack, n, (const float*)d_rgb, (float4*)d_a, (uint32_t)n);
+  DenoiseP D;
+  D.W = width; D.H = height;
+  D.inv_sn2 = 1.0f / (RT_DN_SIGMA_N * RT_DN_SIGMA_N);
+  D.inv_sa2 = 1.0f / (RT_DN_SIGMA_A * RT_DN_SIGMA_A);
+  D.has_albedo = d_alb ? 1 : 0; D.has_normal = d_nrm ? 1 : 0;
+  float sc = RT_DN_SIGMA_C;
+  {
+    Timer t(ctx, RT_K_DENOISE);
+    for (int it = 0; it < RT_DN_ITERS; it++) {
+      D.step = 1 << it;
+      D.inv_sc2 = 1.0f / (sc * sc);
+      LAUNCH(k_dn_atrous, n, D, (const float4*)d_a, (float4*)d_b, (const float4*)d_alb, (const float4*)d_nrm);
+      std::swap(d_a, d_b);
+      sc = sc * 0.5f;
+    }
+    t.stop((1ull << 32) + n);
+  }
+  LAUNCH(k_dn_unpack, n, (const float4*)d_a, (float*)d_rgb, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->profile_on) {
+    std::vector<uint32_t> none;
+    collect_profile(ctx, none);
+  }
+  return RT_OK;
 }
 
 int rt_counters_enable(rt_context* ctx, int enable) {

@@ -34,6 +34,8 @@ def load():
     lib.orc_render.argtypes = [vp, C.POINTER(rt_render_params), C.POINTER(rt_framebuffer), C.c_int, C.POINTER(rt_counters)]
     lib.orc_sample_radiance.argtypes = [vp, C.POINTER(rt_render_params), C.c_int, C.c_int, C.c_int, vp]
     lib.orc_primary_ray.argtypes = [vp, C.POINTER(rt_render_params), C.c_int, C.c_int, C.c_int, C.POINTER(rt_ray)]
+    lib.orc_denoise.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.orc_denoise.restype = None
     lib.orc_photons_build.argtypes = [vp, C.POINTER(rt_render_params), C.POINTER(rt_counters)]
     lib.orc_photons_count.argtypes = [vp, C.c_int]
     lib.orc_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32]
@@ -158,3 +160,16 @@ class OracleScene:
                 self.h = None
         except Exception:
             pass
+
+
+def denoise(rgb, albedo=None, normal=None):
+    """This build's denoise filter restated on the CPU (oracle.cpp orc_denoise)."""
+    lib = load()
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    out = np.zeros_like(rgb)
+    a = np.ascontiguousarray(albedo, np.float32) if albedo is not None else None
+    n = np.ascontiguousarray(normal, np.float32) if normal is not None else None
+    lib.orc_denoise(rgb.ctypes.data, out.ctypes.data, w, h, a.ctypes.data if a is not None else None,
+                    n.ctypes.data if n is not None else None)
+    return out
