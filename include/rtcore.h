@@ -191,7 +191,9 @@ typedef struct rt_render_params {
   int32_t photon_emit_limit;  /* stop emitting after this many photons even if a map is not full (the reference loops
                                  forever then, RayTracer.cpp:277); 0 = 20 * n_photons */
   int32_t photon_max_bounces; /* cap on the photon random walk (the reference has none, RayTracer.cpp:325); 0 = 64 */
-  int32_t reserved[2];
+  int32_t frame_mem_mb;       /* device memory the stage queues of one pass may take, MiB; 0 = 32 GB.  Larger passes
+                                 amortise kernel tails; a host with less free HBM lowers it. */
+  int32_t reserved;
 } rt_render_params;
 
 /* Output images.  Any pointer may be NULL.  Host memory unless `on_device` != 0. */

@@ -102,7 +102,7 @@ class rt_render_params(C.Structure):
                 ("n_photons", C.c_int32), ("photon_radius", C.c_float), ("photon_k", C.c_int32),
                 ("ellipticity_global", C.c_float), ("ellipticity_caustic", C.c_float), ("skip_zero_weight", C.c_int32),
                 ("tile_begin", C.c_int32), ("tile_count", C.c_int32), ("tile_stride", C.c_int32),
-                ("photon_emit_limit", C.c_int32), ("photon_max_bounces", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("photon_emit_limit", C.c_int32), ("photon_max_bounces", C.c_int32), ("frame_mem_mb", C.c_int32), ("reserved", C.c_int32)]
 
 
 class rt_framebuffer(C.Structure):

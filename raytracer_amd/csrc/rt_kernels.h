@@ -66,6 +66,7 @@ struct PassP {
   int32_t aov_sample;    // write hit AOVs for this camera-sample index (-1 none)
   int32_t spp_min, spp_max, adaptive;
   float adaptive_threshold;
+  int32_t discard;       // sizing pass: trace and shade, but leave the accumulator alone
 };
 
 struct FrameBufs {
@@ -728,6 +729,7 @@ RT_HD float t_value(int i) {  // raytracer.h:52-58, index clamped to the table (
 
 // RayTracer.cpp:176-198 per pixel, samples in index order; accum = sum rgb, n, sum of squares rgb, done flag
 RT_KERNEL(k_accumulate, PassP P, FrameBufs F) {
+  if (P.discard || *F.overflow) return;  // a pass whose queues overflowed is re-run in smaller pieces by the host
   for (uint32_t j = RT_TID; j < P.n_pix; j += RT_NTHREADS) {
     uint32_t pixel = F.pixels[j];
     float* a = F.accum + 8 * (size_t)pixel;

@@ -10,7 +10,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,7 +77,7 @@ struct rt_context {
 
   // frame resources
   std::vector<DevMem> frame_mem;
-  size_t frame_key[8] = {0};
+  size_t frame_key[12] = {0};
   RayQ Q[2];
   GroupQ GH, GS;
   GatherQ GQ;
@@ -88,6 +90,10 @@ struct rt_context {
   int32_t* d_hit_face = nullptr;
   DCounters* d_counters = nullptr;
   uint32_t path_budget = 0;
+  // queue sizing: entries per camera sample in the fullest segment, by queue kind (measured by a pilot pass)
+  double fan[4] = {0, 0, 0, 0};
+  size_t fan_key[10] = {0};
+  bool fan_valid = false;
   std::vector<uint32_t> h_pixels;
   size_t pixel_key[6] = {0};
 
@@ -330,6 +336,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   free_pool(ctx->scene_mem);
   ctx->has_scene = false;
+  ctx->fan_valid = false;
   photon_state_free(ctx->photons);
 
   // ---- nodes and instances
@@ -896,6 +903,10 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   LAUNCH_GATHER(k_photon_gather<CNT>, upper, RP.photon_k, G, F, GQ);
 }
 
+// Queue capacities are entries per camera sample of a pass, by kind: f[0] ray queue (levels >= 1), f[1] hard-shadow
+// groups, f[2] soft-shadow groups, f[3] photon gathers.  The worst case (every shade point spawns every child) is
+// branch^(levels-1) entries per sample; real scenes stay far below it, so the capacities come from a measured pilot
+// pass (accumulate_internal) with a margin, and a pass that still overflows is split and re-run.
 struct FramePlan {
   int W, H;
   int levels;         // number of shading levels (max bounce depth + 1)
@@ -903,20 +914,20 @@ struct FramePlan {
   uint32_t budget;    // camera samples per pass
   int n_hard, n_soft; // light counts by shadow kind under these params
   bool photons;
+  double f[4];
 };
 
 int ensure_frame(rt_context* ctx, const FramePlan& fp) {
-  size_t key[8] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft, (size_t)fp.photons};
+  size_t key[12] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft,
+                    (size_t)fp.photons, (size_t)(fp.f[0] * 4096), (size_t)(fp.f[1] * 4096), (size_t)(fp.f[2] * 4096), (size_t)(fp.f[3] * 4096)};
   if (!ctx->frame_mem.empty() && !std::memcmp(key, ctx->frame_key, sizeof key)) return RT_OK;
   free_pool(ctx->frame_mem);
   std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
-  double worst = 1;
-  for (int l = 1; l < fp.levels; l++) worst *= fp.branch;
-  // k_raygen deals 64-path tiles round-robin to NSEG segments; children stay in their parent's segment, so the
-  // worst-case segment length is the level-0 length times the worst-case fan-out.
+  // k_raygen deals 64-path tiles round-robin to NSEG segments; children stay in their parent's segment
   size_t tiles = ((size_t)fp.budget + 63) / 64;
   size_t seg0 = ((tiles + NSEG - 1) / NSEG) * 64;
-  size_t segcap = (size_t)std::min<double>((double)seg0 * worst, 3.0e8 / NSEG);
+  auto cap_of = [&](double f) { return (size_t)std::min<double>(std::ceil((double)seg0 * f) + 64.0, 3.0e8 / NSEG); };
+  size_t segcap = cap_of(std::max(1.0, fp.f[0]));
   size_t qcap = segcap * NSEG;
   int rc;
   void* p;
@@ -935,9 +946,8 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h2 = (float4*)p;
     q.counts = nullptr;
   }
-  auto alloc_group = [&](GroupQ& g, size_t per_entry) {
-    size_t sc = std::min<size_t>(segcap * std::max<size_t>(per_entry, 1), 0x7fffffffu / NSEG);
-    if (per_entry == 0) sc = 1;
+  auto alloc_group = [&](GroupQ& g, double f, bool with_g2) {
+    size_t sc = f > 0 ? cap_of(f) : 1;
     g.segcap = (uint32_t)sc;
     g.nseg = NSEG;
     size_t cap = sc * NSEG;
@@ -945,15 +955,16 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     void* pp;
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g0 = (float4*)pp;
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g1 = (float4*)pp;
-    if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp;
+    g.g2 = nullptr;
+    if (with_g2) { if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp; }
     g.counts = nullptr;
     return (int)RT_OK;
   };
-  if ((rc = alloc_group(ctx->GH, (size_t)fp.n_hard))) return rc;
-  if ((rc = alloc_group(ctx->GS, (size_t)fp.n_soft))) return rc;
+  if ((rc = alloc_group(ctx->GH, fp.n_hard ? fp.f[1] : 0.0, false))) return rc;
+  if ((rc = alloc_group(ctx->GS, fp.n_soft ? fp.f[2] : 0.0, true))) return rc;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.segcap * NSEG * 4, &p))) return rc;
   ctx->d_list2 = (uint32_t*)p;
-  size_t gsegcap = fp.photons ? segcap : 1;
+  size_t gsegcap = fp.photons ? cap_of(fp.f[3]) : 1;
   ctx->GQ.segcap = (uint32_t)gsegcap;
   ctx->GQ.nseg = NSEG;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.a = (float4*)p;
@@ -1100,12 +1111,31 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   if (fp.levels > MAX_LEVELS - 1) return fail(ctx, RT_ERR_UNSUPPORTED, "too many bounce levels");
   fp.branch = 2 + (RP.mc_bounces > 0 ? 1 : 0);
   fp.n_hard = n_hard; fp.n_soft = n_soft; fp.photons = photons_mixed;
-  // bytes of queue memory per camera sample in the worst case; keep the frame resources near 6 GB
-  double worst = std::pow((double)fp.branch, fp.levels - 1);
-  double per_path = worst * (2.0 * 112 + 48.0 * (n_hard + n_soft) + 4.0 * n_soft + (photons_mixed ? 48.0 : 0.0)) + 16;
-  double b = 6.0e9 / per_path;
-  uint32_t budget = (uint32_t)std::min<double>(std::max<double>(b, 65536.0), 4194304.0);
-  budget &= ~63u;
+  const double worst = std::pow((double)fp.branch, fp.levels - 1);
+  const double fworst[4] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0};
+  auto per_path_bytes = [&](const double* f) {
+    return 2.0 * 112 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 + 64.0;
+  };
+  // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
+  // traversal kernels, and HBM is 288 GB
+  double frame_bytes = RP.frame_mem_mb > 0 ? (double)RP.frame_mem_mb * 1048576.0 : 32.0e9;
+  if (const char* e = std::getenv("RT_FRAME_GB")) frame_bytes = std::atof(e) * 1e9;  // developer knob
+  auto budget_for = [&](const double* f) {
+    double b = frame_bytes / per_path_bytes(f);
+    uint32_t v = (uint32_t)std::min<double>(std::max<double>(b, 65536.0), 201326592.0);
+    return v & ~63u;
+  };
+  size_t fkey[10] = {(size_t)W, (size_t)H, (size_t)RP.max_bounces, (size_t)RP.mc_bounces, (size_t)RP.pixel_jitter, (size_t)n_hard,
+                     (size_t)n_soft, (size_t)photons_mixed, (size_t)(RP.skip_zero_weight != 0), (size_t)RP.tile_stride};
+  if (ctx->fan_valid && std::memcmp(fkey, ctx->fan_key, sizeof fkey)) ctx->fan_valid = false;
+  const bool need_pilot = !ctx->fan_valid && worst > 1.0;
+  if (!need_pilot && !ctx->fan_valid) {  // no secondary rays at all: the worst case is exact
+    for (int k = 0; k < 4; k++) ctx->fan[k] = fworst[k];
+    std::memcpy(ctx->fan_key, fkey, sizeof fkey);
+    ctx->fan_valid = true;
+  }
+  for (int k = 0; k < 4; k++) fp.f[k] = need_pilot ? fworst[k] : ctx->fan[k];
+  uint32_t budget = need_pilot ? 131072u : budget_for(fp.f);
   fp.budget = budget;
   if ((rc = ensure_frame(ctx, fp))) return rc;
 
@@ -1158,12 +1188,13 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   F.counters = ctx->d_counters;
 
   std::vector<uint32_t> raw(CNT_TOTAL), counts((MAX_LEVELS + 1) * CNT_KINDS);
+  double seen[4] = {0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
+  bool overflowed = false;
   auto finish_pass = [&](uint64_t paths) -> int {
-    // queue lengths are only needed for the profile's item counts; the overflow flag always
-    size_t first = ctx->profile_on ? 0 : CNT_OVERFLOW;
-    HIP_TRY(hipMemcpyAsync(raw.data() + first, ctx->d_counts + first, (CNT_TOTAL - first) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(raw.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    overflowed = raw[CNT_OVERFLOW] != 0;
     if (ctx->profile_on) {
       for (size_t s = 0; s < counts.size(); s++) {
         uint64_t sum = 0;
@@ -1172,20 +1203,84 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
       }
       collect_profile(ctx, counts);
     }
-    if (raw[CNT_OVERFLOW]) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow");
-    if (ctx->counters_on) ctx->host_paths += paths;
+    auto seg_max = [&](int level, int kind) {
+      uint32_t m = 0;
+      for (uint32_t g = 0; g < NSEG; g++) m = std::max(m, raw[cnt_at(level, kind) + (size_t)g * RT_CSTRIDE]);
+      return (double)m;
+    };
+    double l0 = std::max(64.0, seg_max(0, CNT_Q));
+    const int kinds[4] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ};
+    for (int k = 0; k < 4; k++)
+      for (int l = (k == 0 ? 1 : 0); l <= fp.levels; l++) seen[k] = std::max(seen[k], seg_max(l, kinds[k]) / l0);
+    if (!overflowed && ctx->counters_on) ctx->host_paths += paths;  // paths = 0 for the sizing pass
     return RT_OK;
   };
-  auto pass = [&](const uint32_t* pixels, uint32_t n_pix, int sbase, int ns) -> int {
+  DCounters saved_counters;
+  std::function<int(const uint32_t*, uint32_t, int, int, bool)> pass = [&](const uint32_t* pixels, uint32_t n_pix, int sbase, int ns,
+                                                                           bool discard) -> int {
     PassP Pp = P;
-    Pp.n_pix = n_pix; Pp.sample_base = sbase; Pp.n_samples = ns;
+    Pp.n_pix = n_pix; Pp.sample_base = sbase; Pp.n_samples = ns; Pp.discard = discard ? 1 : 0;
     FrameBufs Ff = F;
     Ff.pixels = pixels;
+    if (ctx->counters_on) HIP_TRY(hipMemcpyAsync(&saved_counters, ctx->d_counters, sizeof saved_counters, hipMemcpyDeviceToHost, ctx->stream));
     int r = ctx->counters_on ? run_pass<true>(ctx, Pp, Ff, fp.levels, n_soft > 0, n_hard > 0, photons_mixed, RP)
                              : run_pass<false>(ctx, Pp, Ff, fp.levels, n_soft > 0, n_hard > 0, photons_mixed, RP);
     if (r) return r;
-    return finish_pass((uint64_t)n_pix * ns);
+    if ((r = finish_pass(discard ? 0 : (uint64_t)n_pix * ns))) return r;
+    if (discard && ctx->counters_on)  // the sizing pass is not part of the frame's work
+      HIP_TRY(hipMemcpy(ctx->d_counters, &saved_counters, sizeof saved_counters, hipMemcpyHostToDevice));
+    if (!overflowed) return RT_OK;
+    // A queue filled up: k_accumulate left the accumulator alone (it checks the flag).  Undo the work counters,
+    // remember to size the queues larger from now on, and redo the pass in two halves.
+    if (ctx->counters_on) HIP_TRY(hipMemcpy(ctx->d_counters, &saved_counters, sizeof saved_counters, hipMemcpyHostToDevice));
+    for (int k = 0; k < 4; k++) ctx->fan[k] = std::min(fworst[k], std::max(ctx->fan[k] * 2.0, seen[k] * 1.5));
+    if (discard) return RT_OK;
+    if (ns > 1) {
+      if ((r = pass(pixels, n_pix, sbase, ns / 2, false))) return r;
+      return pass(pixels, n_pix, sbase + ns / 2, ns - ns / 2, false);
+    }
+    if (n_pix > 64) {
+      uint32_t h = ((n_pix / 2) + 63u) & ~63u;
+      if ((r = pass(pixels, h, sbase, ns, false))) return r;
+      return pass(pixels + h, n_pix - h, sbase, ns, false);
+    }
+    return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow");
   };
+
+  if (need_pilot) {
+    // Pilot: one sample of an evenly strided subset of the 8x8 pixel blocks, results discarded, queues sized for the
+    // worst case; its queue lengths size the real passes.
+    const uint32_t blocks = (n_pix_total + 63) / 64;
+    const uint32_t want = std::min<uint32_t>(blocks, budget / 64);
+    std::vector<uint32_t> sub;
+    sub.reserve((size_t)want * 64);
+    for (uint32_t k = 0; k < want; k++) {
+      uint32_t blk = (uint32_t)(((uint64_t)k * blocks) / want);
+      uint32_t p0 = blk * 64, p1 = std::min(p0 + 64, n_pix_total);
+      sub.insert(sub.end(), ctx->h_pixels.begin() + p0, ctx->h_pixels.begin() + p1);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_pixels2, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pass(ctx->d_pixels2, (uint32_t)sub.size(), begin, 1, true))) return rc;
+    if (overflowed) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow in the sizing pass");
+    double margin = 1.5;
+    if (const char* e = std::getenv("RT_TEST_FAN_SCALE")) margin *= std::atof(e);  // tests: force the overflow / split path
+    for (int k = 0; k < 4; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
+    std::memcpy(ctx->fan_key, fkey, sizeof fkey);
+    ctx->fan_valid = true;
+    for (int k = 0; k < 4; k++) fp.f[k] = ctx->fan[k];
+    budget = budget_for(fp.f);
+    fp.budget = budget;
+    if ((rc = ensure_frame(ctx, fp))) return rc;
+    // ensure_frame re-created the buffers: pixel list, AOVs and the FrameBufs pointers
+    HIP_TRY(hipMemcpyAsync(ctx->d_pixels, ctx->h_pixels.data(), ctx->h_pixels.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(ctx->pixel_key, pkey, sizeof pkey);
+    HIP_TRY(hipMemsetAsync(ctx->d_hit_node, 0xff, (size_t)W * H * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_hit_face, 0xff, (size_t)W * H * 4, ctx->stream));
+    F.path_rad = ctx->d_path_rad;
+    F.hit_node = ctx->d_hit_node;
+    F.hit_face = ctx->d_hit_face;
+    F.overflow = ctx->d_counts + CNT_OVERFLOW;
+  }
 
   if (!adaptive) {
     // fixed sample count: chunks of pixels x chunks of samples
@@ -1195,7 +1290,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
       int ns_max = std::max<int>(1, (int)(budget / np));
       for (int s = 0; s < count; s += ns_max) {
         int ns = std::min(ns_max, count - s);
-        if ((rc = pass(ctx->d_pixels + p0, np, begin + s, ns))) return rc;
+        if ((rc = pass(ctx->d_pixels + p0, np, begin + s, ns, false))) return rc;
       }
       if (track_progress) ctx->pixels_done += np;
     }
@@ -1209,7 +1304,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
       uint32_t np = std::min(pix_chunk, n_pix_total - p0);
       int ns_max = std::max<int>(1, (int)(budget / np));
       for (int s = 0; s < first; s += ns_max)
-        if ((rc = pass(ctx->d_pixels + p0, np, s, std::min(ns_max, first - s)))) return rc;
+        if ((rc = pass(ctx->d_pixels + p0, np, s, std::min(ns_max, first - s), false))) return rc;
       // continue with the active subset
       const uint32_t* cur = ctx->d_pixels + p0;
       uint32_t ncur = np;
@@ -1231,7 +1326,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
         ncur = nact;
         which ^= 1;
         int ns = std::min<int>(std::min<int>(8, RP.spp_max - s), std::max<int>(1, (int)(budget / ncur)));
-        if ((rc = pass(cur, ncur, s, ns))) return rc;
+        if ((rc = pass(cur, ncur, s, ns, false))) return rc;
         s += ns;
       }
       if (track_progress) ctx->pixels_done += np;

@@ -165,3 +165,24 @@ def test_error_paths(emu):
     fresh = emu_ffi.EmuRenderer()
     with pytest.raises(RuntimeError, match="no scene"):
         fresh.TraceRay(random_rays(4, 1))
+
+
+def test_undersized_queues_split_the_pass_and_still_match(monkeypatch):
+    """Queue capacities come from a measured sizing pass; a pass that overflows anyway leaves the accumulator alone and
+    is re-run in halves.  Forced here by shrinking the measured fan-out 20x: the frame must still equal the oracle's."""
+    monkeypatch.setenv("RT_TEST_FAN_SCALE", "0.05")
+    r = emu_ffi.EmuRenderer()
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    r.LoadScene(scene)
+    p = params(128, 128, spp=4, jitter=1, bounces=2)
+    p.frame_mem_mb = 1  # the smallest pass size (65536 camera samples): this frame is exactly one full pass
+    r.counters(enable=True, reset=True)
+    r.profile(enable=True, reset=True)
+    g = r.Render(p)
+    cnt = r.counters()
+    assert r.profile()["raygen"]["launches"] > 3, "the pass was not split: the test did not reach the overflow path"
+    c, ccnt = oracle_ffi.OracleScene(scene).render(p, want_counters=True)
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 2e-5
+    assert (g.radiance[..., 3] == 4).all()
+    for k in ("rays_primary", "rays_secondary", "paths", "shades"):  # work of overflowed attempts is not counted
+        assert cnt[k] == ccnt[k], k
