@@ -11,7 +11,9 @@
 
 #define RT_BIG FLT_MAX            // BIGFLOAT, scene.h:34
 #define RT_MAX_CHAIN 8            // maximum scene-graph depth of an instanced primitive
-#define RT_STACK 32               // BVH traversal stack entries per lane (builder guarantees depth <= 32)
+#ifndef RT_STACK
+#define RT_STACK 32               // BVH traversal stack entries per lane (rt_scene_commit rejects deeper trees)
+#endif
 #define RT_LEAF 0x80000000u
 #define RT_PI_F 3.14159265358979323846f
 #define RT_PI_D 3.14159265358979323846

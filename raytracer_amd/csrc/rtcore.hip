@@ -30,16 +30,28 @@
   } while (0)
 
 #ifndef RT_EMU
-#define LAUNCH(kern, n_items, ...)                                                               \
+#define LAUNCH_N(kern, n_items, cap_, ...)                                                       \
   do {                                                                                           \
     unsigned long long ni_ = (unsigned long long)(n_items);                                      \
     unsigned long long nb_ = (ni_ + RT_BLOCK - 1) / RT_BLOCK;                                    \
     if (nb_ < 1) nb_ = 1;                                                                        \
-    if (nb_ > (unsigned long long)ctx->max_blocks) nb_ = ctx->max_blocks;                        \
+    if (nb_ > (unsigned long long)(cap_)) nb_ = (cap_);                                          \
     hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_BLOCK), 0, ctx->stream, __VA_ARGS__);  \
   } while (0)
+// streaming kernels (raygen, shade, accumulate, ...) and traversal kernels (LDS stack, cache-bound) get their own
+// persistent grid sizes
+#define LAUNCH(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
+#define LAUNCH_T(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks_trace, __VA_ARGS__)
 #else
 #define LAUNCH(kern, n_items, ...) kern(__VA_ARGS__)
+#define LAUNCH_T(kern, n_items, ...) kern(__VA_ARGS__)
+#endif
+
+#ifndef RT_BLOCKS_PER_CU
+#define RT_BLOCKS_PER_CU 8   // streaming kernels: measured 4 -> 8 blocks per CU: k_shade 5.8 -> 4.8 ms per bench step
+#endif
+#ifndef RT_TRACE_BLOCKS_PER_CU
+#define RT_TRACE_BLOCKS_PER_CU 4   // traversal kernels: 32 KB LDS stack per block; 1..6 measured, 4 is fastest
 #endif
 
 namespace {
@@ -63,7 +75,7 @@ struct rt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  int max_blocks = 2048;
+  int max_blocks = 2048, max_blocks_trace = 1024;
   bool has_scene = false;
 
   // committed scene (device)
@@ -301,7 +313,10 @@ int rt_context_create(int device_id, rt_context** out) {
 #ifndef RT_EMU
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
-    ctx->max_blocks = prop.multiProcessorCount * 4;  // 4 x 256-thread blocks per CU: 32 KB LDS stack each
+  {
+    ctx->max_blocks = prop.multiProcessorCount * RT_BLOCKS_PER_CU;
+    ctx->max_blocks_trace = prop.multiProcessorCount * RT_TRACE_BLOCKS_PER_CU;  // LDS stack: RT_STACK x 1 KB per block
+  }
 #endif
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
@@ -536,7 +551,7 @@ int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side
   if ((rc = alloc_dev(ctx, tmp, n * sizeof(rt_ray), &d_r)) || (rc = alloc_dev(ctx, tmp, n * sizeof(rt_hit), &d_h))) { free_pool(tmp); return rc; }
   hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    LAUNCH(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
+    LAUNCH_T(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(hits, d_h, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
@@ -560,7 +575,7 @@ int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t
   hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && t_max) e = hipMemcpyAsync(d_t, t_max, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    LAUNCH(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
+    LAUNCH_T(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(occluded, d_o, n, hipMemcpyDeviceToHost, ctx->stream);
@@ -771,8 +786,8 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
       HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
       {
         Timer t(ctx, RT_K_PHOTON_TRACE);
-        if (ctx->counters_on) LAUNCH(k_photon_trace<true>, count, ctx->ds, PP, O);
-        else LAUNCH(k_photon_trace<false>, count, ctx->ds, PP, O);
+        if (ctx->counters_on) LAUNCH_T(k_photon_trace<true>, count, ctx->ds, PP, O);
+        else LAUNCH_T(k_photon_trace<false>, count, ctx->ds, PP, O);
         t.stop((1ull << 32) + count);
       }
       uint32_t h_cnt[4];
@@ -854,7 +869,7 @@ int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* pho
   do {                                                                                                     \
     unsigned long long nb_ = ((unsigned long long)(n_items) + RT_GATHER_BLOCK - 1) / RT_GATHER_BLOCK;      \
     if (nb_ < 1) nb_ = 1;                                                                                  \
-    if (nb_ > (unsigned long long)ctx->max_blocks * 4) nb_ = (unsigned long long)ctx->max_blocks * 4;      \
+    if (nb_ > (unsigned long long)ctx->max_blocks_trace * 4) nb_ = (unsigned long long)ctx->max_blocks_trace * 4;\
     size_t lds_ = photon_heap_bytes(k_);                                                                   \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);   \
     hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_GATHER_BLOCK), lds_, ctx->stream, __VA_ARGS__);  \
@@ -1030,7 +1045,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
     {
       Timer t(ctx, RT_K_TRACE_CLOSEST);
-      LAUNCH(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, lvl);
+      LAUNCH_T(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, lvl);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
     }
     {
@@ -1040,16 +1055,16 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
-      LAUNCH(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg), ctx->ds, P, F, GH);
+      LAUNCH_T(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg), ctx->ds, P, F, GH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
     }
     if (any_soft) {
       Timer t(ctx, RT_K_SHADOW);
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
-      LAUNCH(k_shadow_soft1<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS);
+      LAUNCH_T(k_shadow_soft1<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS);
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
-        LAUNCH(k_shadow_soft2<CNT>, gs_ub * (uint64_t)(P.shadow_max - P.shadow_min), ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
+        LAUNCH_T(k_shadow_soft2<CNT>, gs_ub * (uint64_t)(P.shadow_max - P.shadow_min), ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
