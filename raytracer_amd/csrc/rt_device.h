@@ -101,6 +101,9 @@ struct DScene {
                         // 1000 base 3 (HaltonSeq<1000>), then n_gloss base 2 and n_gloss base 3 (Halton(i, b) direct)
   int32_t n_inst, n_lights, n_materials, n_gloss;
   DTexColor background, environment;
+  const int32_t* minst;  // indices (into inst) of the mesh instances, depth-first order
+  int32_t n_minst;
+  int32_t pad_;
 };
 #define RT_H2 0
 #define RT_H3 128
@@ -544,46 +547,65 @@ RT_DEV void ray_to_instance(IP I, XP xf, V3 o, V3 dir, ParentRay& pr, V3& p, V3&
   d = xf_dir(m, pr.d);
 }
 
+// Closest hit so far: ray parameter, instance, side, and for meshes the triangle.
+struct Best {
+  float t;
+  int inst;
+  bool front;
+  MeshHit mh;
+};
+RT_DEV void best_init(Best& B) {
+  B.t = RT_BIG; B.inst = -1; B.front = true;
+  B.mh.t = 0; B.mh.u = 0; B.mh.v = 0; B.mh.key = 0; B.mh.face = 0;
+}
+
 // Renderer::TraceRay -> RayTracer::TraverseTree (RayTracer.cpp:373-435): closest hit over every instanced
-// primitive in depth-first node order with strict '<', then the renderable lights.
-template <bool CNT>
-RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
-  float best_t = RT_BIG;
-  int best_inst = -1;
-  bool best_front = true;
-  MeshHit best_mh;
-  best_mh.t = 0; best_mh.u = 0; best_mh.v = 0; best_mh.key = 0; best_mh.face = 0;
+// primitive in depth-first node order with strict '<'.  SPLIT = true is the first phase of the two-phase trace
+// kernels: spheres and planes are tested, mesh instances are only culled against their world box and reported
+// through `mesh_flag` (their BVHs are walked by the second phase, k_trace_mesh).
+template <bool CNT, bool SPLIT>
+RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, bool& mesh_flag, uint32_t* stk, uint32_t stride,
+                              Cnt<CNT>& cnt) {
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   ParentRay pr;
   pr.key = -2; pr.p = o; pr.d = dir;
+  mesh_flag = false;
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     int prim = I->prim;
-    V3 p, d;
-    ray_to_instance(I, xf, o, dir, pr, p, d);
     if (prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
       float tm;       // hit the mesh, so the result is unchanged)
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+      if (SPLIT) { mesh_flag = true; continue; }
     }
+    V3 p, d;
+    ray_to_instance(I, xf, o, dir, pr, p, d);
     cnt.inst();
     float t;
     bool front;
     if (prim == 1) {
       cnt.sphere();
-      if (sphere_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
+      if (sphere_closest(p, d, hitSide, t, front) && t < B.t) { B.t = t; B.inst = i; B.front = front; }
     } else if (prim == 2) {
       cnt.plane();
-      if (plane_closest(p, d, hitSide, t, front) && t < best_t) { best_t = t; best_inst = i; best_front = front; }
+      if (plane_closest(p, d, hitSide, t, front) && t < B.t) { B.t = t; B.inst = i; B.front = front; }
     } else if (prim == 3) {
       V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
       MeshHit mh;
-      if (mesh_closest<CNT>(S, S.meshes[I->mesh], p, d, inv, best_t, mh, stk, stride, cnt) && mh.t < best_t) {
-        best_t = mh.t; best_inst = i; best_mh = mh;
+      if (mesh_closest<CNT>(S, S.meshes[I->mesh], p, d, inv, B.t, mh, stk, stride, cnt) && mh.t < B.t) {
+        B.t = mh.t; B.inst = i; B.mh = mh;
       }
     }
   }
+}
+
+// Hit attributes of the winner (objects.cpp:37-43, 135-138, 303-320), Node::FromNodeCoords back up the chain
+// (scene.h:184-189), then the renderable lights (RayTracer.cpp:413-432).
+RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit) {
+  const float best_t = B.t;
+  const int best_inst = B.inst;
   hit.inst = -1; hit.face = -1; hit.light = -1; hit.front = true; hit.z = RT_BIG;
   hit.p = v3(0, 0, 0); hit.N = v3(0, 0, 0); hit.uvw = v3(0.5f, 0.5f, 0.5f);
   bool any = false;
@@ -598,7 +620,7 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
       p = np; d = nd;
     }
     V3 hp, hn, uvw;
-    bool front = best_front;
+    bool front = B.front;
     if (I.prim == 1) {  // objects.cpp:37-43
       hp = p + (d * best_t);
       hn = normalized(hp);
@@ -611,23 +633,23 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
       uvw = v3((hp.x + 1.0f) * 0.5f, (hp.y + 1.0f) * 0.5f, 0.0f);
     } else {  // objects.cpp:303-320
       const DMesh& M = S.meshes[I.mesh];
-      float u = best_mh.u, v = best_mh.v, w = 1.0f - u - v;
+      float u = B.mh.u, v = B.mh.v, w = 1.0f - u - v;
       uvw = v3(0, 0, 0);
       if (M.has_uvw) {
-        const uint32_t* ft = S.uvw_idx + M.uidx_base + 3 * best_mh.face;
+        const uint32_t* ft = S.uvw_idx + M.uidx_base + 3 * B.mh.face;
         const float* t0 = S.uvw + M.uvw_base + 3 * ft[0];
         const float* t1 = S.uvw + M.uvw_base + 3 * ft[1];
         const float* t2 = S.uvw + M.uvw_base + 3 * ft[2];
         uvw = (v3(t0[0], t0[1], t0[2]) * w) + (v3(t1[0], t1[1], t1[2]) * u) + (v3(t2[0], t2[1], t2[2]) * v);
       }
-      const uint32_t* fn = S.nrm_idx + M.nidx_base + 3 * best_mh.face;
+      const uint32_t* fn = S.nrm_idx + M.nidx_base + 3 * B.mh.face;
       const float* n0 = S.normals + M.nrm_base + 3 * fn[0];
       const float* n1 = S.normals + M.nrm_base + 3 * fn[1];
       const float* n2 = S.normals + M.nrm_base + 3 * fn[2];
       hn = normalized(w * v3(n0[0], n0[1], n0[2]) + u * v3(n1[0], n1[1], n1[2]) + v * v3(n2[0], n2[1], n2[2]));
       hp = p + d * best_t;
       front = dot(d, hn) < 0.0f;
-      hit.face = (int32_t)best_mh.face;
+      hit.face = (int32_t)B.mh.face;
     }
     for (int k = I.depth - 1; k >= 0; k--) {  // Node::FromNodeCoords back up the chain (scene.h:184-189)
       hp = xf_point(chain + 24 * k + 12, hp);
@@ -656,15 +678,26 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
   return any;
 }
 
-// Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
 template <bool CNT>
-RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  Best B;
+  best_init(B);
+  bool mesh_flag;
+  closest_instances<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
+  return finalize_hit(S, o, dir, B, hit);
+}
+
+// Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
+// SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
+template <bool CNT, bool SPLIT>
+RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   ParentRay pr;
   pr.key = -2; pr.p = o; pr.d = dir;
   bool occluded = false;
+  mesh_flag = false;
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     int prim = I->prim;
@@ -674,6 +707,7 @@ RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk,
     if (prim == 3) {
       float tm;
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+      if (SPLIT) { mesh_flag = true; continue; }
     }
     cnt.inst();
     if (prim == 1) {
@@ -688,6 +722,168 @@ RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk,
     }
   }
   return occluded;
+}
+template <bool CNT>
+RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  bool mesh_flag;
+  return any_instances<CNT, false>(S, o, dir, t_max, mesh_flag, stk, stride, cnt);
+}
+
+// ------------------------------------------------------------------ second phase: per-lane walk over mesh instances
+// State of one lane of k_trace_mesh / k_shadow_mesh.  Every lane walks the mesh instances in depth-first order on its
+// own (instance tables are read with per-lane loads here), one BVH step per loop iteration, so that the lanes of a
+// wave can be inside different instances and finished lanes can take new rays while the others keep walking.
+struct MeshWalk {
+  V3 p, d, inv;        // ray in the current instance's space
+  uint32_t cur;        // node / leaf reference
+  uint32_t node_base, tri_base;
+  int sp;
+  int mi;              // next entry of DScene::minst
+  int inst;            // instance being walked
+  bool fast;           // reciprocal direction finite: min3/max3 slab test (bit-identical decisions, see box_test_fast)
+};
+
+// Advances to the next mesh instance whose padded world box and root box the ray hits; false when there is none left.
+// Same tests, in the same order, as closest_instances / any_instances make for a mesh instance.
+template <bool CNT>
+RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, MeshWalk& W, Cnt<CNT>& cnt) {
+  while (W.mi < S.n_minst) {
+    int ii = S.minst[W.mi++];
+    const DInstance& I = S.inst[ii];
+    float tm;
+    if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    const float* chain = S.xf + I.xf_off;
+    V3 p = o, d = dir;
+    for (int k = 0; k < I.depth; k++) {
+      V3 np = xf_point(chain + 24 * k, p);
+      V3 nd = xf_dir(chain + 24 * k, d);
+      p = np; d = nd;
+    }
+    cnt.inst();
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const DMesh& M = S.meshes[I.mesh];
+    bool fast = inv_is_finite(inv);
+    cnt.node();
+    bool hit = fast ? box_test_fast(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)
+                    : box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm);
+    if (!hit) continue;
+    W.p = p; W.d = d; W.inv = inv; W.fast = fast;
+    W.cur = M.root_ref; W.sp = 0; W.inst = ii;
+    W.node_base = M.node_base; W.tri_base = M.tri_base;
+    return true;
+  }
+  return false;
+}
+
+// The 64-byte node record a walking lane stands at.  (A wave-cooperative variant — wanting lanes ranked, sixteen whole
+// nodes per load instruction, quarters handed to their owner through LDS — was built and measured on MI355X: correct,
+// but 7 % slower on the C2 bench than these four per-lane loads; the walk is bound by VALU issue at ~36 % active lanes,
+// not by the texture addresser.  DESIGN.md "What was tried".)
+RT_DEV void fetch_node(const DScene& S, const MeshWalk& W, bool want, float4& n0, float4& n1, float4& n2, float4& n3) {
+  if (want) {
+    const float4* nodes = S.bvh + W.node_base;
+    n0 = nodes[4 * W.cur]; n1 = nodes[4 * W.cur + 1]; n2 = nodes[4 * W.cur + 2]; n3 = nodes[4 * W.cur + 3];
+  }
+}
+
+// One internal-node step of the ordered, pruned closest-hit walk (see mesh_closest_t).  Returns false when the walk of
+// this instance is finished.
+template <bool CNT>
+RT_DEV bool mesh_walk_node_closest(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float bound_t, uint32_t* stk, uint32_t stride,
+                                   Cnt<CNT>& cnt) {
+  float tl, tr;
+  cnt.node(2);
+  bool hl = box_test_fast(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+  bool hr = box_test_fast(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+  if (!W.fast) {  // a zero direction component: the literal hitAABB form (NaN behaviour of FAST_MIN / FAST_MAX)
+    hl = box_test(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+    hr = box_test(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+  }
+  float bound = prune_bound(bound_t);
+  hl = hl && tl <= bound;
+  hr = hr && tr <= bound;
+  uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+  if (hl && hr) {
+    bool left_first = tl <= tr;
+    stk[(W.sp++) * stride] = left_first ? cr : cl;
+    W.cur = left_first ? cl : cr;
+  } else if (hl) {
+    W.cur = cl;
+  } else if (hr) {
+    W.cur = cr;
+  } else {
+    if (W.sp == 0) return false;
+    W.cur = stk[(--W.sp) * stride];
+  }
+  return true;
+}
+// any-hit flavour: fixed child order, pruned against t_max (see mesh_any_t)
+template <bool CNT>
+RT_DEV bool mesh_walk_node_any(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float t_max, uint32_t* stk, uint32_t stride,
+                               Cnt<CNT>& cnt) {
+  float tl, tr;
+  cnt.node(2);
+  bool hl = box_test_fast(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+  bool hr = box_test_fast(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+  if (!W.fast) {
+    hl = box_test(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
+    hr = box_test(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+  }
+  float bound = prune_bound(t_max);
+  hl = hl && tl <= bound;
+  hr = hr && tr <= bound;
+  uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+  if (hl && hr) {
+    stk[(W.sp++) * stride] = cr;
+    W.cur = cl;
+  } else if (hl) {
+    W.cur = cl;
+  } else if (hr) {
+    W.cur = cr;
+  } else {
+    if (W.sp == 0) return false;
+    W.cur = stk[(--W.sp) * stride];
+  }
+  return true;
+}
+// Leaf step of the closest-hit walk: every triangle of the leaf against the instance-local best (tie rules of
+// mesh_closest_t).  Returns false when the walk of this instance is finished.
+template <bool CNT>
+RT_DEV bool mesh_walk_leaf_closest(const DScene& S, MeshWalk& W, MeshHit& L, bool& found, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  const float4* tris = S.tris + W.tri_base;
+  uint32_t count = W.cur & 7u, first = (W.cur & 0x7fffffffu) >> 3;
+  for (uint32_t s = 0; s < count; s++) {
+    float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+    float t, u, v;
+    cnt.tri();
+    if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+      if (t > 0.002f) {
+        uint32_t key = __float_as_uint(a.w);
+        if (t < L.t || (t == L.t && found && key > L.key)) {
+          L.t = t; L.key = key; L.face = __float_as_uint(b.w); L.u = u; L.v = v; found = true;
+        }
+      }
+    }
+  }
+  if (W.sp == 0) return false;
+  W.cur = stk[(--W.sp) * stride];
+  return true;
+}
+// Leaf step of the any-hit walk: `occluded` is set when a triangle has t in (0.002, t_max) (objects.cpp:341-371).
+template <bool CNT>
+RT_DEV bool mesh_walk_leaf_any(const DScene& S, MeshWalk& W, float t_max, bool& occluded, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  const float4* tris = S.tris + W.tri_base;
+  uint32_t count = W.cur & 7u, first = (W.cur & 0x7fffffffu) >> 3;
+  for (uint32_t s = 0; s < count; s++) {
+    float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+    float t, u, v;
+    cnt.tri();
+    if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
+      if (t > 0.002f && t < t_max) { occluded = true; return false; }
+  }
+  if (W.sp == 0) return false;
+  W.cur = stk[(--W.sp) * stride];
+  return true;
 }
 
 // ------------------------------------------------------------------ textures (texture.cpp:106-140, scene.h:312-397)

@@ -48,6 +48,15 @@ struct GatherQ {  // photon-map lookups deferred to k_photon_gather (materials.c
   uint32_t nseg;
 };
 
+struct MeshQ {       // work items of the second (mesh) phase of the trace kernels
+  uint4* item4;      // closest-hit: ray-queue entry, best t (bits), best instance, front flag
+  uint2* item2;      // shadow: group, sample index
+  uint32_t* counts;  // segment lengths
+  uint32_t* cursor;  // per segment, RT_CSTRIDE words apart: next unclaimed item (claimed 1..64 at a time by the walkers)
+  uint32_t segcap;
+  uint32_t nseg;
+};
+
 struct PassP {
   // camera constants, computed on the host exactly as RunThread does (RayTracer.cpp:95-101, 15-22)
   float X[3], Y[3], Z[3], pos[3];
@@ -231,27 +240,57 @@ RT_KERNEL(k_raygen, DScene S, PassP P, FrameBufs F, RayQ Q) {
 }
 
 // ------------------------------------------------------------------------------------------------ trace
+// Closest hit in two phases.
+//   k_trace_closest  every lane takes one ray through the instance table (wave-uniform loop, scalar-loaded entries):
+//                    spheres and planes are intersected, mesh instances only culled against their world box.  A ray
+//                    that reaches no mesh box is finished here (hit record written); the others become work items.
+//   k_trace_mesh     walks the BVHs of the items' mesh instances.  Waves are persistent: a lane that finishes its
+//                    ray claims the next item (one atomic per wave per refill), so the lanes of a wave stay busy
+//                    although rays need very different numbers of steps.  (Measured before the split: 38 % of the
+//                    lanes active in VALU instructions of the one-phase kernel, profiles/r01_v3_pmc_mem_summary.json.)
+// The result is the one RayTracer::TraverseTree defines (minimum t, strict '<' in depth-first instance order): the
+// second phase compares (t, instance index) against the first phase's best.
+RT_DEV void write_hit(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, uint32_t idx, uint4 m, const Hit& h, int level) {
+  uint32_t flags = (h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8);
+  Q.h0[idx] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+  Q.h1[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
+  Q.h2[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float(flags));
+  if (level == 0 && F.hit_node && (int)m.z == P.aov_sample) {
+    F.hit_node[m.y] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
+    F.hit_face[m.y] = h.light >= 0 ? -1 : h.face;
+  }
+}
+
 template <bool CNT>
-RT_DEV void trace_closest_body(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, int level, uint32_t* stk, uint32_t stride) {
+RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
+  RT_STACK_DECL
   Cnt<CNT> cnt;
   uint32_t traced = 0;
   RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
-    if (!seg_valid) continue;
     uint32_t idx = seg_base_ + (uint32_t)seg_e;
-    uint4 m = Q.q3[idx];
-    if (m.w & (1u << 16)) continue;        // re-shade entry: hit record was written by k_shade (lights.cpp:172-183)
-    float4 a = Q.q0[idx], b = Q.q1[idx];
-    Hit h;
-    traced++;
-    // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
-    scene_closest<CNT>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), level == 0 ? 1 : 3, h, stk, stride, cnt);
-    uint32_t flags = (h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8);
-    Q.h0[idx] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-    Q.h1[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
-    Q.h2[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float(flags));
-    if (level == 0 && F.hit_node && (int)m.z == P.aov_sample) {
-      F.hit_node[m.y] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
-      F.hit_face[m.y] = h.light >= 0 ? -1 : h.face;
+    bool need_mesh = false;
+    Best B;
+    best_init(B);
+    if (seg_valid) {
+      uint4 m = Q.q3[idx];
+      if (!(m.w & (1u << 16))) {  // (re-shade entries carry a hit record written by k_shade, lights.cpp:172-183)
+        float4 a = Q.q0[idx], b = Q.q1[idx];
+        V3 o = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z);
+        traced++;
+        // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
+        closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
+        if (!need_mesh) {
+          Hit h;
+          finalize_hit(S, o, dir, B, h);
+          write_hit(S, P, F, Q, idx, m, h, level);
+        }
+      }
+    }
+    uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      uint4 it;
+      it.x = idx; it.y = __float_as_uint(B.t); it.z = (uint32_t)B.inst; it.w = B.front ? 1u : 0u;
+      MQ.item4[wi] = it;
     }
   RT_SEG_END
   if (CNT) {
@@ -260,10 +299,132 @@ RT_DEV void trace_closest_body(const DScene& S, const PassP& P, const FrameBufs&
     if (traced) rt_atomic_add_u64(level == 0 ? &F.counters->rays_primary : &F.counters->rays_secondary, traced);
   }
 }
+
+// ---- item claiming for the persistent second-phase kernels
+// Lanes whose `idle` is set ask for an item of segment `seg`; returns the item index or RT_NONE.  `exhausted` is
+// set (wave-uniform) when the segment has no items left after this claim.
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 32u   // lanes that must wait for service (finish / claim / next instance) before a wave runs it
+#endif
+#ifndef RT_NODE_MIN
+#define RT_NODE_MIN 8u      // see the inner-node loop of k_trace_mesh
+#endif
+RT_DEV uint32_t claim_items(bool idle, const MeshQ& MQ, uint32_t seg, bool& exhausted) {
+  uint32_t n_seg = MQ.counts[seg * RT_CSTRIDE];
+  if (n_seg > MQ.segcap) n_seg = MQ.segcap;
+  exhausted = false;
+#ifndef RT_EMU
+  unsigned long long mask = __ballot(idle);
+  uint32_t n = (uint32_t)__popcll(mask);
+  if (n == 0) return RT_NONE;
+  uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)rt_lane() == leader) base = atomicAdd(MQ.cursor + seg * RT_CSTRIDE, n);
+  base = (uint32_t)__shfl((int)base, leader);
+#else
+  if (!idle) return RT_NONE;
+  uint32_t n = 1, rank = 0;
+  uint32_t base = MQ.cursor[seg * RT_CSTRIDE];
+  MQ.cursor[seg * RT_CSTRIDE] = base + 1;
+#endif
+  exhausted = base + n >= n_seg;
+  if (idle && base + rank < n_seg) return seg * MQ.segcap + base + rank;
+  return RT_NONE;
+}
+RT_DEV uint32_t count_lanes(bool pred) {
+#ifndef RT_EMU
+  return (uint32_t)__popcll(__ballot(pred));
+#else
+  return pred ? 1u : 0u;
+#endif
+}
+
+enum { RT_ST_IDLE = 0, RT_ST_NEXT = 1, RT_ST_WALK = 2, RT_ST_DONE = 3 };
+// Lane states of the second-phase kernels: IDLE no ray; NEXT has a ray, wants its next mesh instance; WALK inside a BVH;
+// DONE all instances walked, result not yet written.  Everything except WALK is "service" work (finish, claim, enter
+// the next instance); it is batched: the wave only runs it when at least RT_REFILL_MIN lanes wait for it (or nobody
+// walks), so that this code, too, is issued for many lanes at a time.
+
 template <bool CNT>
-RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, int level) {
+RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
   RT_STACK_DECL
-  trace_closest_body<CNT>(S, P, F, Q, level, stk, stride);
+  Cnt<CNT> cnt;
+  const uint32_t nseg = MQ.nseg;
+  uint32_t seg = rt_wave_id() % nseg, segs_done = 0;  // wave-uniform: home segment first, then the others (work stealing)
+  const uint32_t refill_min = RT_REFILL_MIN < RT_WAVE ? RT_REFILL_MIN : RT_WAVE;
+  int state = RT_ST_IDLE;
+  uint32_t ray_idx = 0;
+  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0), winv = v3(0, 0, 0);
+  Best B;
+  best_init(B);
+  MeshWalk W;
+  W.p = W.d = W.inv = v3(0, 0, 0);
+  W.cur = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  MeshHit L;
+  L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
+  bool lfound = false;
+  for (;;) {
+    uint32_t n_walk = count_lanes(state == RT_ST_WALK);
+    if (RT_WAVE - n_walk >= refill_min || n_walk == 0) {
+      // ---- service: write finished rays, claim new items, enter the next mesh instance
+      if (state == RT_ST_DONE) {
+        Hit h;
+        finalize_hit(S, o, dir, B, h);
+        write_hit(S, P, F, Q, ray_idx, Q.q3[ray_idx], h, level);
+        state = RT_ST_IDLE;
+      }
+      if (segs_done < nseg) {
+        bool exhausted;
+        uint32_t wi = claim_items(state == RT_ST_IDLE, MQ, seg, exhausted);
+        if (wi != RT_NONE) {
+          uint4 it = MQ.item4[wi];
+          ray_idx = it.x;
+          float4 a = Q.q0[ray_idx], b = Q.q1[ray_idx];
+          o = v3(a.x, a.y, a.z); dir = v3(b.x, b.y, b.z);
+          winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+          best_init(B);
+          B.t = __uint_as_float(it.y); B.inst = (int)it.z; B.front = it.w != 0;
+          W.mi = 0;
+          state = RT_ST_NEXT;
+        }
+        if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
+      }
+      if (state == RT_ST_NEXT) {
+        if (mesh_walk_next<CNT>(S, o, dir, winv, W, cnt)) {
+          L.t = RT_BIG; lfound = false;
+          state = RT_ST_WALK;
+        } else {
+          state = RT_ST_DONE;
+        }
+      }
+      if (count_lanes(state != RT_ST_IDLE) == 0 && segs_done >= nseg) break;
+    }
+    // ---- BVH steps, "while-while": inner nodes until every walking lane stands at a leaf (or is done with its
+    // instance), then the leaves together — the leaf code is never issued for a wave that is mostly at inner nodes
+    // Inner nodes until (nearly) every walking lane stands at a leaf: the loop ends when fewer than RT_NODE_MIN lanes
+    // are still at inner nodes while at least as many wait at leaves; the stragglers walk on in the next round.
+    bool more = true;
+    for (;;) {
+      bool at_node = state == RT_ST_WALK && more && !(W.cur & RT_LEAF);
+      uint32_t n_node = count_lanes(at_node);
+      if (n_node == 0 || (n_node < RT_NODE_MIN && count_lanes(state == RT_ST_WALK && more && (W.cur & RT_LEAF)) >= RT_NODE_MIN)) break;
+      float4 n0, n1, n2, n3;
+      fetch_node(S, W, at_node, n0, n1, n2, n3);
+      if (at_node) more = mesh_walk_node_closest<CNT>(W, n0, n1, n2, n3, L.t < B.t ? L.t : B.t, stk, stride, cnt);
+    }
+    if (state == RT_ST_WALK && more && (W.cur & RT_LEAF))
+      more = mesh_walk_leaf_closest<CNT>(S, W, L, lfound, stk, stride, cnt);
+    if (state == RT_ST_WALK && !more) {
+      // TraverseTree's strict '<' in depth-first order: an equal t wins only for an earlier instance
+      if (lfound && (L.t < B.t || (L.t == B.t && W.inst < B.inst))) { B.t = L.t; B.inst = W.inst; B.mh = L; }
+      state = RT_ST_NEXT;
+    }
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    cnt.flush_closest(F.counters);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -592,43 +753,24 @@ RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, G
 }
 
 // ------------------------------------------------------------------------------------------------ shadows
-// Hard shadows: one ray per group (DirectLight, and PointLight of size 0 where the reference's 16..128 rays are
-// identical).
-template <bool CNT>
-RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G) {
-  RT_STACK_DECL
-  Cnt<CNT> cnt;
-  uint32_t rays = 0;
-  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
-    if (!seg_valid) continue;
-    uint32_t g = seg_base_ + (uint32_t)seg_e;
-    float4 g1 = G.g1[g];
-    float4 g0 = G.g0[g];
-    V3 Pp = v3(g0.x, g0.y, g0.z);
-    const DLight& L = S.lights[__float_as_uint(g0.w)];
-    V3 d;
-    float tmax;
-    if (L.kind == 2) {
-      d = -v3(L.direction[0], L.direction[1], L.direction[2]);
-      tmax = RT_BIG;
-    } else {
-      V3 toLight = v3(L.position[0], L.position[1], L.position[2]) - Pp;
-      tmax = length(toLight);
-      d = toLight / tmax;
-    }
-    rays++;
-    if (!scene_any<CNT>(S, Pp, d, tmax, stk, stride, cnt)) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
-  RT_SEG_END
-  if (CNT) {
-    cnt.flush(F.counters);
-    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
+// Shadow rays in the same two phases as the closest-hit kernels: k_shadow_hard / k_shadow_soft1 / k_shadow_soft2 test
+// spheres and planes and cull the mesh instances' world boxes; rays that reach a mesh box undecided become items of
+// k_shadow_mesh, which walks the BVHs (any-hit) with persistent, refilling waves.
+RT_DEV void hard_shadow_ray(const DScene& S, float4 g0, V3& Pp, V3& d, float& tmax) {
+  Pp = v3(g0.x, g0.y, g0.z);
+  const DLight& L = S.lights[__float_as_uint(g0.w)];
+  if (L.kind == 2) {  // DirectLight::Illuminate, lights.h:45
+    d = -v3(L.direction[0], L.direction[1], L.direction[2]);
+    tmax = RT_BIG;
+  } else {            // PointLight of size 0: the reference's 16..128 rays are identical
+    V3 toLight = v3(L.position[0], L.position[1], L.position[2]) - Pp;
+    tmax = length(toLight);
+    d = toLight / tmax;
   }
 }
-
-// Soft shadows, PointLight::Illuminate (lights.cpp:34-60): sample j of group g.
-template <bool CNT>
-RT_DEV bool soft_sample_lit(const DScene& S, const PassP& P, float4 g0, float4 g2, uint32_t j, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
-  V3 Pp = v3(g0.x, g0.y, g0.z);
+// Soft shadows, PointLight::Illuminate (lights.cpp:34-60): the ray of sample j of a group.
+RT_DEV void soft_shadow_ray(const DScene& S, const PassP& P, float4 g0, float4 g2, uint32_t j, V3& Pp, V3& d, float& dist) {
+  Pp = v3(g0.x, g0.y, g0.z);
   const DLight& L = S.lights[__float_as_uint(g0.w)];
   V3 position = v3(L.position[0], L.position[1], L.position[2]);
   float size = L.size * P.light_size_scale;
@@ -646,29 +788,141 @@ RT_DEV bool soft_sample_lit(const DScene& S, const PassP& P, float4 g0, float4 g
   float offsetV = r * sinf(angle);
   V3 lsp = position + (tangent * offsetU) + (bitangent * offsetV);
   V3 toLight = lsp - Pp;
-  float dist = length(toLight);
-  V3 d = toLight / dist;
-  return !scene_any<CNT>(S, Pp, d, dist, stk, stride, cnt);
+  dist = length(toLight);
+  d = toLight / dist;
 }
 
-// phase 1: the first shadow_min samples of every group, one lane per (group, sample)
+// Hard shadows: one ray per group (DirectLight, and PointLight of size 0).
 template <bool CNT>
-RT_KERNEL(k_shadow_soft1, DScene S, PassP P, FrameBufs F, GroupQ G) {
+RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   RT_STACK_DECL
-  uint32_t n1 = (uint32_t)P.shadow_min;
   Cnt<CNT> cnt;
   uint32_t rays = 0;
-  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, n1)
-    if (!seg_valid) continue;
-    uint32_t g = seg_base_ + (uint32_t)(seg_e / n1), j = (uint32_t)(seg_e % n1);
-    rays++;
-    if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
+  RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
+    uint32_t g = seg_base_ + (uint32_t)seg_e;
+    bool need_mesh = false;
+    if (seg_valid) {
+      float4 g1 = G.g1[g];
+      V3 Pp, d;
+      float tmax;
+      hard_shadow_ray(S, G.g0[g], Pp, d, tmax);
+      rays++;
+      bool occ = any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
+      if (occ) need_mesh = false;
+      else if (!need_mesh) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+    }
+    uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      uint2 it;
+      it.x = g; it.y = 0;
+      MQ.item2[wi] = it;
+    }
   RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
     if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
   }
 }
+
+// Soft shadows, phases of PointLight::Illuminate's sample loop: `j0` .. `j0 + nj - 1` of every group (`list` = null:
+// all groups of the queue; else the groups listed, i.e. those not fully lit after the first shadow_min samples).
+template <bool CNT>
+RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list, const uint32_t* list_counts, uint32_t j0,
+          uint32_t nj, MeshQ MQ) {
+  RT_STACK_DECL
+  Cnt<CNT> cnt;
+  uint32_t rays = 0;
+  const uint32_t* counts = list ? list_counts : G.counts;
+  RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
+    uint32_t g = 0, j = 0;
+    bool need_mesh = false;
+    if (seg_valid) {
+      uint32_t e = seg_base_ + (uint32_t)(seg_e / nj);
+      g = list ? list[e] : e;
+      j = j0 + (uint32_t)(seg_e % nj);
+      V3 Pp, d;
+      float dist;
+      soft_shadow_ray(S, P, G.g0[g], G.g2[g], j, Pp, d, dist);
+      rays++;
+      bool occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
+      if (occ) need_mesh = false;
+      else if (!need_mesh) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
+    }
+    uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      uint2 it;
+      it.x = g; it.y = j;
+      MQ.item2[wi] = it;
+    }
+  RT_SEG_END
+  if (CNT) {
+    cnt.flush(F.counters);
+    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
+  }
+}
+
+// Second phase of the shadow kernels: any-hit walk over the mesh instances for the undecided rays.
+template <bool CNT, bool SOFT>
+RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
+  RT_STACK_DECL
+  Cnt<CNT> cnt;
+  const uint32_t nseg = MQ.nseg;
+  uint32_t seg = rt_wave_id() % nseg, segs_done = 0;
+  const uint32_t refill_min = RT_REFILL_MIN < RT_WAVE ? RT_REFILL_MIN : RT_WAVE;
+  int state = RT_ST_IDLE;
+  uint32_t group = 0;
+  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0), winv = v3(0, 0, 0);
+  float tmax = 0.0f;
+  MeshWalk W;
+  W.p = W.d = W.inv = v3(0, 0, 0);
+  W.cur = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  for (;;) {
+    uint32_t n_walk = count_lanes(state == RT_ST_WALK);
+    if (RT_WAVE - n_walk >= refill_min || n_walk == 0) {  // service, batched as in k_trace_mesh
+      if (state == RT_ST_DONE) {  // no mesh occludes the ray either: it is lit
+        if (SOFT) {
+          rt_atomic_add_u32((uint32_t*)&G.g2[group].z, 1u);
+        } else {
+          float4 g1 = G.g1[group];
+          add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+        }
+        state = RT_ST_IDLE;
+      }
+      if (segs_done < nseg) {
+        bool exhausted;
+        uint32_t wi = claim_items(state == RT_ST_IDLE, MQ, seg, exhausted);
+        if (wi != RT_NONE) {
+          uint2 it = MQ.item2[wi];
+          group = it.x;
+          if (SOFT) soft_shadow_ray(S, P, G.g0[group], G.g2[group], it.y, o, dir, tmax);
+          else hard_shadow_ray(S, G.g0[group], o, dir, tmax);
+          winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+          W.mi = 0;
+          state = RT_ST_NEXT;
+        }
+        if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
+      }
+      if (state == RT_ST_NEXT) state = mesh_walk_next<CNT>(S, o, dir, winv, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
+      if (count_lanes(state != RT_ST_IDLE) == 0 && segs_done >= nseg) break;
+    }
+    bool occluded = false, more = true;
+    for (;;) {
+      bool at_node = state == RT_ST_WALK && more && !(W.cur & RT_LEAF);
+      uint32_t n_node = count_lanes(at_node);
+      if (n_node == 0 || (n_node < RT_NODE_MIN && count_lanes(state == RT_ST_WALK && more && (W.cur & RT_LEAF)) >= RT_NODE_MIN)) break;
+      float4 n0, n1, n2, n3;
+      fetch_node(S, W, at_node, n0, n1, n2, n3);
+      if (at_node) more = mesh_walk_node_any<CNT>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+    }
+    if (state == RT_ST_WALK && more && (W.cur & RT_LEAF)) more = mesh_walk_leaf_any<CNT>(S, W, tmax, occluded, stk, stride, cnt);
+    if (state == RT_ST_WALK) {
+      if (occluded) state = RT_ST_IDLE;
+      else if (!more) state = RT_ST_NEXT;
+    }
+  }
+  if (CNT) cnt.flush(F.counters);
+}
+
 // early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues
 RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, uint32_t* list2, uint32_t* n2) {
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
@@ -687,24 +941,6 @@ RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, uint32_t* list2,
     uint32_t li = seg_push(more, n2, sw_.s, G.segcap, F.overflow);
     if (li != RT_NONE) list2[li] = g;
   RT_SEG_END
-}
-// phase 2: samples shadow_min .. shadow_max-1 of the groups that were not fully lit
-template <bool CNT>
-RT_KERNEL(k_shadow_soft2, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
-  RT_STACK_DECL
-  uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
-  Cnt<CNT> cnt;
-  uint32_t rays = 0;
-  RT_SEG_BEGIN(n2, G.nseg, G.segcap, nr)
-    if (!seg_valid) continue;
-    uint32_t g = list2[seg_base_ + (uint32_t)(seg_e / nr)], j = (uint32_t)P.shadow_min + (uint32_t)(seg_e % nr);
-    rays++;
-    if (soft_sample_lit<CNT>(S, P, G.g0[g], G.g2[g], j, stk, stride, cnt)) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
-  RT_SEG_END
-  if (CNT) {
-    cnt.flush(F.counters);
-    if (rays) rt_atomic_add_u64(&F.counters->rays_shadow, rays);
-  }
 }
 RT_KERNEL(k_shadow_soft_final, PassP P, FrameBufs F, GroupQ G, const uint32_t* list2, const uint32_t* n2) {
   RT_SEG_BEGIN(n2, G.nseg, G.segcap, 1u)

@@ -82,17 +82,18 @@ struct rt_context {
   std::vector<DevMem> scene_mem;
   DScene ds;
   rt_camera camera;
-  int n_nodes = 0, n_hard_lights = 0, n_soft_capable = 0, n_gloss = 0;
+  int n_nodes = 0, n_hard_lights = 0, n_soft_capable = 0, n_gloss = 0, n_minst = 0;
   std::vector<rt_light> lights;
   std::vector<DInstance> h_inst;
   std::vector<rt_material> h_materials;
 
   // frame resources
   std::vector<DevMem> frame_mem;
-  size_t frame_key[12] = {0};
+  size_t frame_key[16] = {0};
   RayQ Q[2];
   GroupQ GH, GS;
   GatherQ GQ;
+  MeshQ MQ, MH, MS;
   uint32_t* d_list2 = nullptr;
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
   float4* d_path_rad = nullptr;
@@ -103,7 +104,7 @@ struct rt_context {
   DCounters* d_counters = nullptr;
   uint32_t path_budget = 0;
   // queue sizing: entries per camera sample in the fullest segment, by queue kind (measured by a pilot pass)
-  double fan[4] = {0, 0, 0, 0};
+  double fan[7] = {0, 0, 0, 0, 0, 0, 0};
   size_t fan_key[10] = {0};
   bool fan_valid = false;
   std::vector<uint32_t> h_pixels;
@@ -525,6 +526,12 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if ((rc = upload(ctx, ctx->scene_mem, texels, &D.texels))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, lights, &D.lights))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, hal, &D.halton))) return rc;
+  std::vector<int32_t> minst;
+  for (size_t i = 0; i < inst.size(); i++)
+    if (inst[i].prim == RT_PRIM_MESH) minst.push_back((int32_t)i);
+  if ((rc = upload(ctx, ctx->scene_mem, minst, &D.minst))) return rc;
+  D.n_minst = (int32_t)minst.size();
+  ctx->n_minst = D.n_minst;
   D.n_inst = (int)inst.size();
   D.n_lights = (int)lights.size();
   D.n_materials = (int)sc->n_materials;
@@ -592,7 +599,10 @@ namespace {
 
 // Device layout of the queue-length words: [level][kind][segment * RT_CSTRIDE]; then the overflow flag and the
 // active-pixel counter.  Level l's ray queue lengths live at (l, CNT_Q); its children are counted at (l + 1, CNT_Q).
-enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4, CNT_KINDS = 5 };
+enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4,
+       CNT_MQ = 5, CNT_MH = 6, CNT_MS1 = 7, CNT_MS2 = 8,        // mesh-phase item queues: closest, hard shadow, soft shadow phases
+       CUR_MQ = 9, CUR_MH = 10, CUR_MS1 = 11, CUR_MS2 = 12,     // their claim cursors
+       CNT_KINDS = 13 };
 constexpr int MAX_LEVELS = 8;
 constexpr uint32_t NSEG = 64;
 constexpr size_t CNT_SLAB = (size_t)NSEG * RT_CSTRIDE;                       // words per (level, kind)
@@ -929,12 +939,14 @@ struct FramePlan {
   uint32_t budget;    // camera samples per pass
   int n_hard, n_soft; // light counts by shadow kind under these params
   bool photons;
-  double f[4];
+  bool meshes;        // the scene has mesh instances: the second (mesh) phase of the trace kernels runs
+  double f[7];        // + f[4] closest-hit mesh items, f[5] hard-shadow mesh items, f[6] soft-shadow mesh items
 };
 
 int ensure_frame(rt_context* ctx, const FramePlan& fp) {
-  size_t key[12] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft,
-                    (size_t)fp.photons, (size_t)(fp.f[0] * 4096), (size_t)(fp.f[1] * 4096), (size_t)(fp.f[2] * 4096), (size_t)(fp.f[3] * 4096)};
+  size_t key[16] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft,
+                    (size_t)fp.photons, (size_t)(fp.f[0] * 4096), (size_t)(fp.f[1] * 4096), (size_t)(fp.f[2] * 4096), (size_t)(fp.f[3] * 4096),
+                    (size_t)(fp.f[4] * 4096), (size_t)(fp.f[5] * 4096), (size_t)(fp.f[6] * 4096), (size_t)fp.meshes};
   if (!ctx->frame_mem.empty() && !std::memcmp(key, ctx->frame_key, sizeof key)) return RT_OK;
   free_pool(ctx->frame_mem);
   std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
@@ -986,6 +998,20 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
   ctx->GQ.counts = nullptr;
+  auto alloc_meshq = [&](MeshQ& q, double f, size_t item_bytes) {
+    size_t sc = (fp.meshes && f > 0) ? cap_of(f) : 1;
+    q.segcap = (uint32_t)sc;
+    q.nseg = NSEG;
+    q.counts = q.cursor = nullptr;
+    void* pp;
+    int r = alloc_dev(ctx, ctx->frame_mem, sc * NSEG * item_bytes, &pp);
+    q.item4 = (uint4*)pp;
+    q.item2 = (uint2*)pp;
+    return r;
+  };
+  if ((rc = alloc_meshq(ctx->MQ, fp.f[4], 16))) return rc;
+  if ((rc = alloc_meshq(ctx->MH, fp.n_hard ? fp.f[5] : 0.0, 8))) return rc;
+  if ((rc = alloc_meshq(ctx->MS, fp.n_soft ? fp.f[6] : 0.0, 8))) return rc;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 16, &p))) return rc;
   ctx->d_path_rad = (float4*)p;
   size_t npx = (size_t)fp.W * fp.H;
@@ -1043,9 +1069,18 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     GQ.counts = ctx->d_counts + cnt_at(lvl, CNT_GQ);
     uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
+    const bool meshes = ctx->n_minst > 0;
+    auto meshq = [&](const MeshQ& base, int kind_cnt, int kind_cur) {
+      MeshQ q = base;
+      q.counts = ctx->d_counts + cnt_at(lvl, kind_cnt);
+      q.cursor = ctx->d_counts + cnt_at(lvl, kind_cur);
+      return q;
+    };
     {
       Timer t(ctx, RT_K_TRACE_CLOSEST);
-      LAUNCH_T(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, lvl);
+      MeshQ MQ = meshq(ctx->MQ, CNT_MQ, CUR_MQ);
+      LAUNCH_T(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, MQ, lvl);
+      if (meshes) LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
     }
     {
@@ -1055,16 +1090,26 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
-      LAUNCH_T(k_shadow_hard<CNT>, std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg), ctx->ds, P, F, GH);
+      MeshQ MH = meshq(ctx->MH, CNT_MH, CUR_MH);
+      uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
+      LAUNCH_T(k_shadow_hard<CNT>, gh_ub, ctx->ds, P, F, GH, MH);
+      if (meshes) LAUNCH_T((k_shadow_mesh<CNT, false>), std::min<uint64_t>(gh_ub, (uint64_t)MH.segcap * MH.nseg), ctx->ds, P, F, GH, MH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
     }
     if (any_soft) {
       Timer t(ctx, RT_K_SHADOW);
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
-      LAUNCH_T(k_shadow_soft1<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS);
+      MeshQ MS1 = meshq(ctx->MS, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, CNT_MS2, CUR_MS2);
+      const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
+      LAUNCH_T(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+               (uint32_t)P.shadow_min, MS1);
+      if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
-        LAUNCH_T(k_shadow_soft2<CNT>, gs_ub * (uint64_t)(P.shadow_max - P.shadow_min), ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
+        uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
+        LAUNCH_T(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
+                 (uint32_t)P.shadow_min, nr, MS2);
+        if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
@@ -1127,9 +1172,12 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   fp.branch = 2 + (RP.mc_bounces > 0 ? 1 : 0);
   fp.n_hard = n_hard; fp.n_soft = n_soft; fp.photons = photons_mixed;
   const double worst = std::pow((double)fp.branch, fp.levels - 1);
-  const double fworst[4] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0};
+  const bool meshes = ctx->n_minst > 0;
+  const double soft_rays = std::max(RP.shadow_min, RP.shadow_max - RP.shadow_min);
+  const double fworst[7] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
+                            meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0};
   auto per_path_bytes = [&](const double* f) {
-    return 2.0 * 112 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 + 64.0;
+    return 2.0 * 112 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
   };
   // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
   // traversal kernels, and HBM is 288 GB
@@ -1141,15 +1189,17 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     return v & ~63u;
   };
   size_t fkey[10] = {(size_t)W, (size_t)H, (size_t)RP.max_bounces, (size_t)RP.mc_bounces, (size_t)RP.pixel_jitter, (size_t)n_hard,
-                     (size_t)n_soft, (size_t)photons_mixed, (size_t)(RP.skip_zero_weight != 0), (size_t)RP.tile_stride};
+                     (size_t)n_soft, (size_t)photons_mixed, (size_t)(RP.skip_zero_weight != 0) + 2 * (size_t)RP.shadow_min + 512 * (size_t)RP.shadow_max,
+                     (size_t)RP.tile_stride};
   if (ctx->fan_valid && std::memcmp(fkey, ctx->fan_key, sizeof fkey)) ctx->fan_valid = false;
   const bool need_pilot = !ctx->fan_valid && worst > 1.0;
   if (!need_pilot && !ctx->fan_valid) {  // no secondary rays at all: the worst case is exact
-    for (int k = 0; k < 4; k++) ctx->fan[k] = fworst[k];
+    for (int k = 0; k < 7; k++) ctx->fan[k] = fworst[k];
     std::memcpy(ctx->fan_key, fkey, sizeof fkey);
     ctx->fan_valid = true;
   }
-  for (int k = 0; k < 4; k++) fp.f[k] = need_pilot ? fworst[k] : ctx->fan[k];
+  for (int k = 0; k < 7; k++) fp.f[k] = need_pilot ? fworst[k] : ctx->fan[k];
+  fp.meshes = meshes;
   uint32_t budget = need_pilot ? 131072u : budget_for(fp.f);
   fp.budget = budget;
   if ((rc = ensure_frame(ctx, fp))) return rc;
@@ -1203,7 +1253,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   F.counters = ctx->d_counters;
 
   std::vector<uint32_t> raw(CNT_TOTAL), counts((MAX_LEVELS + 1) * CNT_KINDS);
-  double seen[4] = {0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
+  double seen[7] = {0, 0, 0, 0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
   bool overflowed = false;
   auto finish_pass = [&](uint64_t paths) -> int {
     HIP_TRY(hipMemcpyAsync(raw.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1224,9 +1274,10 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
       return (double)m;
     };
     double l0 = std::max(64.0, seg_max(0, CNT_Q));
-    const int kinds[4] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ};
-    for (int k = 0; k < 4; k++)
+    const int kinds[7] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ, CNT_MQ, CNT_MH, CNT_MS1};
+    for (int k = 0; k < 7; k++)
       for (int l = (k == 0 ? 1 : 0); l <= fp.levels; l++) seen[k] = std::max(seen[k], seg_max(l, kinds[k]) / l0);
+    for (int l = 0; l <= fp.levels; l++) seen[6] = std::max(seen[6], seg_max(l, CNT_MS2) / l0);
     if (!overflowed && ctx->counters_on) ctx->host_paths += paths;  // paths = 0 for the sizing pass
     return RT_OK;
   };
@@ -1248,7 +1299,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     // A queue filled up: k_accumulate left the accumulator alone (it checks the flag).  Undo the work counters,
     // remember to size the queues larger from now on, and redo the pass in two halves.
     if (ctx->counters_on) HIP_TRY(hipMemcpy(ctx->d_counters, &saved_counters, sizeof saved_counters, hipMemcpyHostToDevice));
-    for (int k = 0; k < 4; k++) ctx->fan[k] = std::min(fworst[k], std::max(ctx->fan[k] * 2.0, seen[k] * 1.5));
+    for (int k = 0; k < 7; k++) ctx->fan[k] = std::min(fworst[k], std::max(ctx->fan[k] * 2.0, seen[k] * 1.5));
     if (discard) return RT_OK;
     if (ns > 1) {
       if ((r = pass(pixels, n_pix, sbase, ns / 2, false))) return r;
@@ -1279,10 +1330,10 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     if (overflowed) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow in the sizing pass");
     double margin = 1.5;
     if (const char* e = std::getenv("RT_TEST_FAN_SCALE")) margin *= std::atof(e);  // tests: force the overflow / split path
-    for (int k = 0; k < 4; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
+    for (int k = 0; k < 7; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
     std::memcpy(ctx->fan_key, fkey, sizeof fkey);
     ctx->fan_valid = true;
-    for (int k = 0; k < 4; k++) fp.f[k] = ctx->fan[k];
+    for (int k = 0; k < 7; k++) fp.f[k] = ctx->fan[k];
     budget = budget_for(fp.f);
     fp.budget = budget;
     if ((rc = ensure_frame(ctx, fp))) return rc;
