@@ -23,35 +23,85 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP_PER_STEP = 32
-WIDTH, HEIGHT = 1920, 1080
-SCENE = os.path.join(ROOT, "scenes", "c2_mesh_room.xml")
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3    # FP32 vector peak
 
 
-def make_params(rank):
-    from raytracer_amd import default_params
-    p = default_params()
-    p.width, p.height = WIDTH, HEIGHT
-    p.spp_min = p.spp_max = 65536  # fixed sample count; the range below selects what this call renders
-    p.sample_begin = rank * SPP_PER_STEP
-    p.sample_count = SPP_PER_STEP
-    p.pixel_jitter = 1
-    p.max_bounces = 3
-    p.photons = 0
-    p.seed_lo = 1
-    return p
+class Config:
+    """One BASELINE.json configuration.  The driver runs the default (c2, configs[1]: the largest that BASELINE quotes
+    on ONE MI355X); the others are selectable with --config for the measurements recorded in BASELINE.md / DESIGN.md."""
+
+    def __init__(self, name, workload, width, height, spp_per_step, scene, tweak):
+        self.name, self.workload, self.width, self.height = name, workload, width, height
+        self.spp_per_step, self.scene_fn, self.tweak = spp_per_step, scene, tweak
+
+    def scene(self):
+        return self.scene_fn()
+
+    def params(self, rank):
+        from raytracer_amd import default_params
+        p = default_params()
+        p.width, p.height = self.width, self.height
+        p.spp_min = p.spp_max = 65536  # fixed sample count; the range below selects what this call renders
+        p.sample_begin = rank * self.spp_per_step
+        p.sample_count = self.spp_per_step
+        p.pixel_jitter = 1
+        p.max_bounces = 3
+        p.photons = 0
+        p.seed_lo = 1
+        self.tweak(p)
+        return p
 
 
-def cpu_baseline(scene, target_seconds=12.0):
+def _load(path):
+    def f():
+        from raytracer_amd import Scene
+        return Scene.load(os.path.join(ROOT, path))
+    return f
+
+
+def _stress():
+    from raytracer_amd import Scene
+    return Scene.stress(seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160)
+
+
+def _c1(p):
+    p.pixel_jitter, p.max_bounces, p.light_size_scale = 0, 0, 0.0
+
+
+def _c3(p):
+    p.mc_bounces = 2
+
+
+def _c4(p):
+    p.photons = 1
+
+
+CONFIGS = {
+    "c1": Config("c1", "C1: spheres + planes scene (tests/golden/scenes/spheres_room.xml), Blinn + hard point-light shadows, "
+                 "pixel centre, 0 bounces", 800, 600, 1, _load("tests/golden/scenes/spheres_room.xml"), _c1),
+    "c2": Config("c2", "C2: scenes/c2_mesh_room.xml (scene_5 layout, 2 procedural meshes, 81k triangles), 3 bounces "
+                 "reflection+refraction, hard point-light shadows, photons off", 1920, 1080, 32, _load("scenes/c2_mesh_room.xml"),
+                 lambda p: None),
+    "c3": Config("c3", "C3: scenes/c3_cornell_textured.xml (Cornell box, checker floor, brick wall, cloud environment), Monte-Carlo "
+                 "indirect diffuse 2 bounces + 3 specular bounces, soft shadows 16..128 rays; 8 of the 1024 spp per step", 3840, 2160, 8,
+                 _load("scenes/c3_cornell_textured.xml"), _c3),
+    "c4": Config("c4", "C4: Cornell box (tests/golden/scenes/cornell_box.xml), 2 x 100k photons rebuilt every step, k=128 r=3 gather, "
+                 "soft shadows, 3 bounces", 1920, 1080, 8, _load("tests/golden/scenes/cornell_box.xml"), _c4),
+    "c5": Config("c5", "C5: synthetic stress scene, 12.6 M triangles in one BVH (2048 icospheres + displaced ground), 2 sphere "
+                 "lights, 3 bounces; 4 of the 4096 spp per step", 3840, 2160, 4, _stress, lambda p: None),
+}
+
+
+def cpu_baseline(cfg, scene, target_seconds=12.0):
     """The CPU oracle (reference-structured restatement: Θ(nodes) scene-graph walk, BVH visiting both children, std::thread
     over 32x32 tiles) timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
     cores = min(16, os.cpu_count() or 1)
     orc = oracle_ffi.OracleScene(scene)
-    p = make_params(0)
+    WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
+    p = cfg.params(0)
     p.sample_count = 1
     t0 = time.perf_counter()
     _, cnt = orc.render(p, cores, want_counters=True)
@@ -73,7 +123,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
 
     import torch
     import torch.distributed as dist
@@ -89,15 +142,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from raytracer_amd import Renderer, Scene, distributed
-    scene = Scene.load(SCENE)
+    scene = cfg.scene()
     r = Renderer(local_rank)
     r.LoadScene(scene)
-    p = make_params(rank)
+    p = cfg.params(rank)
     accum = torch.zeros(WIDTH * HEIGHT * 8, dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step():
         accum.zero_()
         torch.cuda.synchronize()
+        if p.photons:
+            r.BuildPhotonMaps(p)  # GeneratePhotons is part of every BeginRender (RayTracer.cpp:24-40)
         # blocking render of this rank's sample range into `accum`, then the sample-split exchange:
         # one RCCL sum-reduce of the accumulators to rank 0 over xGMI
         distributed.render_partition(r, p, accum)
@@ -136,22 +191,31 @@ def main():
 
     if rank == 0:
         # final image of the last step (outside the timed region): sanity that the accumulators hold a frame
-        pr = make_params(0)
+        pr = cfg.params(0)
         img = r.resolve(pr, accum.data_ptr())
         n_expected = SPP_PER_STEP * world
         assert abs(float(img.radiance[..., 3].mean()) - n_expected) < 1e-3, "accumulator does not hold the expected samples"
 
-        tc = prof["trace_closest"]
-        # SURVEY §8d algorithmic bytes of the closest-hit kernel: 48 B per ray (32 B ray in, 16 B hit out) + 32 B per BVH box
-        # tested (two per 64-byte node fetch) + 48 B per triangle slot + 96 B per instance transform pair.
+        # SURVEY §8d algorithmic bytes of the two closest-hit kernels: 48 B per ray or work item (32 B ray in, 16 B hit
+        # out) + 32 B per BVH box tested (two per 64-byte node fetch) + 48 B per triangle slot + 96 B per instance
+        # transform pair.  All BVH node / triangle work of the closest-hit stage happens in k_trace_mesh; the instance
+        # table (spheres, planes, mesh world boxes) is walked by k_trace_closest.
         tc_rays = cnt["rays_primary"] + cnt["rays_secondary"]
-        tc_bytes = 48.0 * tc_rays + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"] + 96.0 * cnt["closest_inst_tests"]
-        tc_flops = 36.0 * cnt["closest_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"]
+        first_inst = cnt["closest_inst_tests"] - cnt["mesh_inst_tests"]
+        kern = {
+            "k_trace_closest": (prof["trace_closest"], 48.0 * tc_rays + 96.0 * first_inst, 36.0 * first_inst),
+            "k_trace_mesh": (prof["trace_mesh"],
+                             48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"]
+                             + 96.0 * cnt["mesh_inst_tests"],
+                             36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"]),
+        }
+        dom = max(kern, key=lambda k: kern[k][0]["ms"])   # the kernel with the most time in the timed region
+        tc, tc_bytes, tc_flops = kern[dom]
         launches_per_step = tc["launches"] / max(args.steps, 1)
         avg_ms = tc["ms"] / max(tc["launches"], 1)
         achieved = (tc_bytes / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_trace_closest.json")
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{dom}_{cfg.name}.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -162,24 +226,23 @@ def main():
             "metric": "Mrays/s", "value": total_rays_per_step * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: scenes/c2_mesh_room.xml (scene_5 layout, 2 procedural meshes, 81k triangles), "
-                                   f"{WIDTH}x{HEIGHT}, {SPP_PER_STEP} spp per GPU per step, 3 bounces reflection+refraction, "
-                                   "hard point-light shadows, photons off, Philox seed 1",
+            "config": {"workload": f"{cfg.workload}; {WIDTH}x{HEIGHT}, {SPP_PER_STEP} spp per GPU per step, Philox seed 1",
+                       "triangles": scene.n_triangles(),
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
                        "partition": "sample-range split, RCCL sum-reduce of the accumulator" if world > 1 else "single GPU",
                        "kernel_ms_per_step": kernel_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": tc_bytes / max(launches_per_step, 1),
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "valu_tflops": (tc_flops / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                          "valu_frac": ((tc_flops / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e12) / VALU_PEAK_TFLOPS if avg_ms > 0 else 0.0,
-                         "note": "scene working set (~9 MB of BVH nodes + triangle slots) is cache resident: the kernel is "
-                                 "latency/VALU bound; HBM fraction is reported as the contract asks, the FP32 VALU fraction beside it"},
+                         "note": "algorithmic bytes per SURVEY 8d; when the scene's BVH + triangle slots fit the L2 / Infinity Cache "
+                                 "the kernel is latency / VALU bound rather than HBM bound, so the FP32 VALU fraction is reported beside it"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene)
+            out["cpu_baseline"] = cpu_baseline(cfg, scene)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

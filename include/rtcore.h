@@ -215,9 +215,14 @@ typedef struct rt_counters {
   uint64_t paths;
   /* the share of inst_tests / node_visits / tri_tests done by the closest-hit kernel (roofline attribution) */
   uint64_t closest_inst_tests, closest_node_visits, closest_tri_tests;
+  /* mesh instances entered, mesh work items and rays finished by the second (mesh) phase of the closest-hit kernels */
+  uint64_t mesh_inst_tests, mesh_items;
 } rt_counters;
 
-enum { RT_K_RAYGEN = 0, RT_K_TRACE_CLOSEST, RT_K_SHADE, RT_K_SHADOW, RT_K_ACCUM, RT_K_PHOTON_TRACE, RT_K_PHOTON_GATHER, RT_K_DENOISE, RT_K_COUNT };
+/* RT_K_TRACE_CLOSEST / RT_K_SHADOW: first phase (instance table: spheres, planes, mesh world boxes);
+ * RT_K_TRACE_MESH / RT_K_SHADOW_MESH: second phase (BVH walk of the rays that reach a mesh). */
+enum { RT_K_RAYGEN = 0, RT_K_TRACE_CLOSEST, RT_K_SHADE, RT_K_SHADOW, RT_K_ACCUM, RT_K_PHOTON_TRACE, RT_K_PHOTON_GATHER, RT_K_DENOISE,
+       RT_K_TRACE_MESH, RT_K_SHADOW_MESH, RT_K_COUNT };
 /* HIP-event timing of the library's own kernels on its own stream. */
 typedef struct rt_profile {
   double ms[RT_K_COUNT];

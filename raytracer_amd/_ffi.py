@@ -15,7 +15,8 @@ RT_HIT_FRONT, RT_HIT_BACK, RT_HIT_FRONT_AND_BACK = 1, 2, 3
 RT_PRIM_NONE, RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_MESH = 0, 1, 2, 3
 RT_SAMPLER_PHILOX, RT_SAMPLER_PCG_HALTON = 0, 1
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECT, RT_LIGHT_POINT = 1, 2, 3
-RT_K_NAMES = ["raygen", "trace_closest", "shade", "shadow", "accum", "photon_trace", "photon_gather", "denoise"]
+RT_K_NAMES = ["raygen", "trace_closest", "shade", "shadow", "accum", "photon_trace", "photon_gather", "denoise", "trace_mesh",
+              "shadow_mesh"]
 
 
 class rt_mat34(C.Structure):
@@ -114,13 +115,13 @@ class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("rays_primary", "rays_secondary", "rays_shadow", "rays_photon", "inst_tests", "sphere_tests",
                  "plane_tests", "node_visits", "tri_tests", "shades", "tex_evals", "photon_visits", "gathers", "paths",
-                 "closest_inst_tests", "closest_node_visits", "closest_tri_tests")]
+                 "closest_inst_tests", "closest_node_visits", "closest_tri_tests", "mesh_inst_tests", "mesh_items")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-RT_K_COUNT = 8
+RT_K_COUNT = len(RT_K_NAMES)
 
 
 class rt_profile(C.Structure):

@@ -118,6 +118,7 @@ struct DCounters {  // mirrors rt_counters
   unsigned long long inst_tests, sphere_tests, plane_tests, node_visits, tri_tests;
   unsigned long long shades, tex_evals, photon_visits, gathers, paths;
   unsigned long long closest_inst_tests, closest_node_visits, closest_tri_tests;
+  unsigned long long mesh_inst_tests, mesh_items;
 };
 
 // per-lane work counters kept in registers by the counted kernel variants
@@ -149,6 +150,7 @@ template <> struct Cnt<true> {
   }
 };
 template <> struct Cnt<false> {
+  LaneCnt c;  // never touched; lets counted-only code compile in both variants
   RT_MEM void inst(uint32_t = 1) {}
   RT_MEM void sphere() {}
   RT_MEM void plane() {}

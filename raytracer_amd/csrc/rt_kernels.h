@@ -364,6 +364,7 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
   MeshHit L;
   L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
   bool lfound = false;
+  uint32_t n_items = 0;
   for (;;) {
     uint32_t n_walk = count_lanes(state == RT_ST_WALK);
     if (RT_WAVE - n_walk >= refill_min || n_walk == 0) {
@@ -386,6 +387,7 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
           best_init(B);
           B.t = __uint_as_float(it.y); B.inst = (int)it.z; B.front = it.w != 0;
           W.mi = 0;
+          n_items++;
           state = RT_ST_NEXT;
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
@@ -426,6 +428,8 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
   if (CNT) {
     cnt.flush(F.counters);
     cnt.flush_closest(F.counters);
+    if (cnt.c.inst) rt_atomic_add_u64(&F.counters->mesh_inst_tests, cnt.c.inst);
+    if (n_items) rt_atomic_add_u64(&F.counters->mesh_items, n_items);
   }
 }
 

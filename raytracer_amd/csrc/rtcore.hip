@@ -1077,11 +1077,15 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       return q;
     };
     {
-      Timer t(ctx, RT_K_TRACE_CLOSEST);
       MeshQ MQ = meshq(ctx->MQ, CNT_MQ, CUR_MQ);
+      Timer t(ctx, RT_K_TRACE_CLOSEST);
       LAUNCH_T(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, MQ, lvl);
-      if (meshes) LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+      if (meshes) {
+        Timer t2(ctx, RT_K_TRACE_MESH);
+        LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
+        t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
+      }
     }
     {
       Timer t(ctx, RT_K_SHADE);
@@ -1093,8 +1097,12 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       MeshQ MH = meshq(ctx->MH, CNT_MH, CUR_MH);
       uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
       LAUNCH_T(k_shadow_hard<CNT>, gh_ub, ctx->ds, P, F, GH, MH);
-      if (meshes) LAUNCH_T((k_shadow_mesh<CNT, false>), std::min<uint64_t>(gh_ub, (uint64_t)MH.segcap * MH.nseg), ctx->ds, P, F, GH, MH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
+      if (meshes) {
+        Timer t2(ctx, RT_K_SHADOW_MESH);
+        LAUNCH_T((k_shadow_mesh<CNT, false>), std::min<uint64_t>(gh_ub, (uint64_t)MH.segcap * MH.nseg), ctx->ds, P, F, GH, MH);
+        t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MH));
+      }
     }
     if (any_soft) {
       Timer t(ctx, RT_K_SHADOW);
