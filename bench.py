@@ -231,7 +231,7 @@ def main():
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
                        "partition": "sample-range split, RCCL sum-reduce of the accumulator" if world > 1 else "single GPU",
-                       "kernel_ms_per_step": kernel_ms},
+                       "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": tc_bytes / max(launches_per_step, 1),

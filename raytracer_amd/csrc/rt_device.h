@@ -737,13 +737,17 @@ RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk,
 // wave can be inside different instances and finished lanes can take new rays while the others keep walking.
 struct MeshWalk {
   V3 p, d, inv;        // ray in the current instance's space
-  uint32_t cur;        // node / leaf reference
+  uint32_t cur;        // node / leaf reference to process next, RT_NOREF when the stack has run empty
+  uint32_t pend;       // a leaf reached earlier and not yet intersected (0 = none), see k_trace_mesh
   uint32_t node_base, tri_base;
   int sp;
   int mi;              // next entry of DScene::minst
   int inst;            // instance being walked
   bool fast;           // reciprocal direction finite: min3/max3 slab test (bit-identical decisions, see box_test_fast)
 };
+#define RT_NOREF 0xFFFFFFFFu
+RT_DEV bool ref_is_node(uint32_t r) { return !(r & RT_LEAF); }                  // (RT_NOREF has the leaf bit)
+RT_DEV bool ref_is_leaf(uint32_t r) { return (r & RT_LEAF) && r != RT_NOREF; }
 
 // Advances to the next mesh instance whose padded world box and root box the ray hits; false when there is none left.
 // Same tests, in the same order, as closest_instances / any_instances make for a mesh instance.
@@ -770,7 +774,7 @@ RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, MeshWalk& W, 
                     : box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm);
     if (!hit) continue;
     W.p = p; W.d = d; W.inv = inv; W.fast = fast;
-    W.cur = M.root_ref; W.sp = 0; W.inst = ii;
+    W.cur = M.root_ref; W.pend = 0; W.sp = 0; W.inst = ii;
     W.node_base = M.node_base; W.tri_base = M.tri_base;
     return true;
   }
@@ -788,11 +792,18 @@ RT_DEV void fetch_node(const DScene& S, const MeshWalk& W, bool want, float4& n0
   }
 }
 
-// One internal-node step of the ordered, pruned closest-hit walk (see mesh_closest_t).  Returns false when the walk of
-// this instance is finished.
-template <bool CNT>
-RT_DEV bool mesh_walk_node_closest(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float bound_t, uint32_t* stk, uint32_t stride,
-                                   Cnt<CNT>& cnt) {
+RT_DEV uint32_t walk_pop(MeshWalk& W, uint32_t* stk, uint32_t stride) {
+  if (W.sp == 0) return RT_NOREF;
+  return stk[(--W.sp) * stride];
+}
+
+// One internal-node step of the walk: both children's slab tests, pruned against `bound_t`; W.cur becomes the next
+// reference (RT_NOREF when nothing is left).  ORDERED: the nearer child first (closest hit); otherwise the fixed
+// child order of the any-hit walk (see mesh_any_t).  Written without nested branches: one predicated LDS write (both
+// children hit), one predicated LDS read (neither hit), selects for the rest.
+template <bool CNT, bool ORDERED>
+RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float bound_t, uint32_t* stk, uint32_t stride,
+                           Cnt<CNT>& cnt) {
   float tl, tr;
   cnt.node(2);
   bool hl = box_test_fast(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
@@ -805,55 +816,25 @@ RT_DEV bool mesh_walk_node_closest(MeshWalk& W, float4 n0, float4 n1, float4 n2,
   hl = hl && tl <= bound;
   hr = hr && tr <= bound;
   uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
-  if (hl && hr) {
-    bool left_first = tl <= tr;
-    stk[(W.sp++) * stride] = left_first ? cr : cl;
-    W.cur = left_first ? cl : cr;
-  } else if (hl) {
-    W.cur = cl;
-  } else if (hr) {
-    W.cur = cr;
-  } else {
-    if (W.sp == 0) return false;
-    W.cur = stk[(--W.sp) * stride];
-  }
-  return true;
+  bool left_first = ORDERED ? (tl <= tr) : true;
+  bool both = hl && hr, any = hl || hr;
+  uint32_t nearc = (hl && (!hr || left_first)) ? cl : cr;
+  uint32_t farc = left_first ? cr : cl;
+  bool pop = !any && W.sp > 0;
+  int spn = W.sp - (pop ? 1 : 0);
+  uint32_t next = any ? nearc : RT_NOREF;
+  if (pop) next = stk[spn * stride];
+  if (both) stk[spn * stride] = farc;
+  W.sp = spn + (both ? 1 : 0);
+  W.cur = next;
 }
-// any-hit flavour: fixed child order, pruned against t_max (see mesh_any_t)
+
+// Leaf step of the closest-hit walk: every triangle of leaf `ref` against the instance-local best (tie rules of
+// mesh_closest_t).
 template <bool CNT>
-RT_DEV bool mesh_walk_node_any(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float t_max, uint32_t* stk, uint32_t stride,
-                               Cnt<CNT>& cnt) {
-  float tl, tr;
-  cnt.node(2);
-  bool hl = box_test_fast(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-  bool hr = box_test_fast(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
-  if (!W.fast) {
-    hl = box_test(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-    hr = box_test(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
-  }
-  float bound = prune_bound(t_max);
-  hl = hl && tl <= bound;
-  hr = hr && tr <= bound;
-  uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
-  if (hl && hr) {
-    stk[(W.sp++) * stride] = cr;
-    W.cur = cl;
-  } else if (hl) {
-    W.cur = cl;
-  } else if (hr) {
-    W.cur = cr;
-  } else {
-    if (W.sp == 0) return false;
-    W.cur = stk[(--W.sp) * stride];
-  }
-  return true;
-}
-// Leaf step of the closest-hit walk: every triangle of the leaf against the instance-local best (tie rules of
-// mesh_closest_t).  Returns false when the walk of this instance is finished.
-template <bool CNT>
-RT_DEV bool mesh_walk_leaf_closest(const DScene& S, MeshWalk& W, MeshHit& L, bool& found, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+RT_DEV void mesh_walk_leaf_closest(const DScene& S, const MeshWalk& W, uint32_t ref, MeshHit& L, bool& found, Cnt<CNT>& cnt) {
   const float4* tris = S.tris + W.tri_base;
-  uint32_t count = W.cur & 7u, first = (W.cur & 0x7fffffffu) >> 3;
+  uint32_t count = ref & 7u, first = (ref & 0x7fffffffu) >> 3;
   for (uint32_t s = 0; s < count; s++) {
     float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
     float t, u, v;
@@ -867,25 +848,21 @@ RT_DEV bool mesh_walk_leaf_closest(const DScene& S, MeshWalk& W, MeshHit& L, boo
       }
     }
   }
-  if (W.sp == 0) return false;
-  W.cur = stk[(--W.sp) * stride];
-  return true;
 }
-// Leaf step of the any-hit walk: `occluded` is set when a triangle has t in (0.002, t_max) (objects.cpp:341-371).
+// Leaf step of the any-hit walk: true when a triangle of leaf `ref` has t in (0.002, t_max) (objects.cpp:341-371).
 template <bool CNT>
-RT_DEV bool mesh_walk_leaf_any(const DScene& S, MeshWalk& W, float t_max, bool& occluded, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+RT_DEV bool mesh_walk_leaf_any(const DScene& S, const MeshWalk& W, uint32_t ref, float t_max, Cnt<CNT>& cnt) {
   const float4* tris = S.tris + W.tri_base;
-  uint32_t count = W.cur & 7u, first = (W.cur & 0x7fffffffu) >> 3;
+  uint32_t count = ref & 7u, first = (ref & 0x7fffffffu) >> 3;
+  bool occluded = false;
   for (uint32_t s = 0; s < count; s++) {
     float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
     float t, u, v;
     cnt.tri();
     if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
-      if (t > 0.002f && t < t_max) { occluded = true; return false; }
+      if (t > 0.002f && t < t_max) { occluded = true; break; }
   }
-  if (W.sp == 0) return false;
-  W.cur = stk[(--W.sp) * stride];
-  return true;
+  return occluded;
 }
 
 // ------------------------------------------------------------------ textures (texture.cpp:106-140, scene.h:312-397)

@@ -20,7 +20,9 @@ struct RayQ {
   float4* q1;  // dir.xyz,    weight.g
   float4* q2;  // parent absorption.rgb, weight.b
   uint4* q3;   // path slot, pixel index, camera sample index, meta
-  float4* h0;  // hit p.xyz, z
+  float4* r0;  // closest hit as the trace kernels leave it: t, barycentric u, v (meshes), (instance + 1) | front << 31
+  uint32_t* rf;  // ... and the face index (meshes); the hit attributes are computed by k_shade (finalize_hit)
+  float4* h0;  // re-shade entries only (written by k_shade, lights.cpp:172-183): hit p.xyz, z
   float4* h1;  // hit N.xyz, instance (int bits)
   float4* h2;  // hit uvw.xyz, flags (bit0 front, bits 8.. light+1)
   uint32_t* counts;  // nseg segment lengths, RT_CSTRIDE words apart
@@ -132,6 +134,29 @@ RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t seg
     return RT_NONE;
   }
   return seg * segcap + pos;
+}
+#endif
+
+// Counts the lanes with `pred` per run of equal `key` (runs are contiguous lanes: consecutive work items of one
+// shadow group) and adds the count to the run's word with ONE atomic per run instead of one per lane.  Every lane of
+// the wave must call it; lanes without an item pass pred = false and key = RT_NONE.  (One atomic per lit shadow ray
+// was what bound k_shadow_soft: 5 G atomics per C3 bench step.)
+#ifndef RT_EMU
+RT_DEV void run_count_add(bool pred, uint32_t key, uint32_t* word) {
+  const uint32_t lane = rt_lane();
+  uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+  unsigned long long heads = __ballot(lane == 0 || prev != key);
+  unsigned long long lit = __ballot(pred);
+  if (!((heads >> lane) & 1ull) || key == RT_NONE) return;
+  unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+  uint32_t end = above ? lane + 1 + (uint32_t)(__ffsll((long long)above) - 1) : 64u;
+  unsigned long long mask = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+  uint32_t n = (uint32_t)__popcll(lit & mask);
+  if (n) atomicAdd(word, n);
+}
+#else
+RT_DEV void run_count_add(bool pred, uint32_t key, uint32_t* word) {
+  if (pred && key != RT_NONE) *word += 1u;
 }
 #endif
 
@@ -250,15 +275,16 @@ RT_KERNEL(k_raygen, DScene S, PassP P, FrameBufs F, RayQ Q) {
 //                    lanes active in VALU instructions of the one-phase kernel, profiles/r01_v3_pmc_mem_summary.json.)
 // The result is the one RayTracer::TraverseTree defines (minimum t, strict '<' in depth-first instance order): the
 // second phase compares (t, instance index) against the first phase's best.
-RT_DEV void write_hit(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, uint32_t idx, uint4 m, const Hit& h, int level) {
-  uint32_t flags = (h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8);
-  Q.h0[idx] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-  Q.h1[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
-  Q.h2[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float(flags));
-  if (level == 0 && F.hit_node && (int)m.z == P.aov_sample) {
-    F.hit_node[m.y] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
-    F.hit_face[m.y] = h.light >= 0 ? -1 : h.face;
-  }
+RT_DEV void write_raw(const RayQ& Q, uint32_t idx, const Best& B) {
+  Q.r0[idx] = make_float4(B.t, B.mh.u, B.mh.v, __uint_as_float((uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u)));
+  Q.rf[idx] = B.mh.face;
+}
+RT_DEV void read_raw(const RayQ& Q, uint32_t idx, Best& B) {
+  float4 r = Q.r0[idx];
+  uint32_t w = __float_as_uint(r.w);
+  B.t = r.x; B.mh.u = r.y; B.mh.v = r.z; B.mh.t = r.x; B.mh.key = 0;
+  B.inst = (int)(w & 0x7fffffffu) - 1; B.front = (w >> 31) != 0;
+  B.mh.face = Q.rf[idx];
 }
 
 template <bool CNT>
@@ -279,11 +305,7 @@ RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int
         traced++;
         // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
         closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
-        if (!need_mesh) {
-          Hit h;
-          finalize_hit(S, o, dir, B, h);
-          write_hit(S, P, F, Q, idx, m, h, level);
-        }
+        if (!need_mesh) write_raw(Q, idx, B);
       }
     }
     uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
@@ -341,11 +363,27 @@ RT_DEV uint32_t count_lanes(bool pred) {
 }
 
 enum { RT_ST_IDLE = 0, RT_ST_NEXT = 1, RT_ST_WALK = 2, RT_ST_DONE = 3 };
+#ifdef RT_WALK_STATS   // developer build: wave-level iteration / active-lane tallies of k_trace_mesh<true>
+__device__ unsigned long long g_walk_stats[16];
+#define WSTAT(i, v) do { if (CNT && rt_lane() == 0) ws[i] += (v); } while (0)
+#else
+#define WSTAT(i, v) do {} while (0)
+#endif
 // Lane states of the second-phase kernels: IDLE no ray; NEXT has a ray, wants its next mesh instance; WALK inside a BVH;
 // DONE all instances walked, result not yet written.  Everything except WALK is "service" work (finish, claim, enter
 // the next instance); it is batched: the wave only runs it when at least RT_REFILL_MIN lanes wait for it (or nobody
 // walks), so that this code, too, is issued for many lanes at a time.
 
+// Exit condition every wave of the persistent kernels reaches even if the step logic were wrong: far above any real
+// walk (a wave of the 12.6 M-triangle stress scene takes < 2^21 steps), reported to the host through the overflow word.
+#define RT_WALK_GUARD (1u << 25)
+#define RT_WALK_ABORT 0xDEADu
+#ifndef RT_NODE_BATCH
+#define RT_NODE_BATCH 4
+#endif
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 24u     // parked leaves that trigger a leaf step while enough lanes still stand at inner nodes
+#endif
 template <bool CNT>
 RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
   RT_STACK_DECL
@@ -360,19 +398,47 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
   best_init(B);
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
-  W.cur = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
   MeshHit L;
   L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
   bool lfound = false;
-  uint32_t n_items = 0;
+  uint32_t n_items = 0, guard = 0;
+#ifdef RT_WALK_STATS
+  unsigned long long ws[16] = {0};
+#endif
+  // One step per iteration, chosen for the whole wave: service (finish rays, claim items, enter the next instance),
+  // an inner-node step, or a leaf step.  A lane that reaches a leaf parks it (one per lane) and walks on from its stack,
+  // so node steps keep the walking lanes busy and the parked leaves are intersected together.  Walking on before the
+  // parked leaf is intersected only means pruning against a slightly older bound: the result (minimum t, tie rules by
+  // key) does not depend on the order.  Service is batched: it runs when at least RT_REFILL_MIN lanes wait for it (or
+  // nothing else is left to do) — checked every step, so lanes whose walk was short do not idle until the longest walk
+  // of the wave ends (measured before this: 21 of 64 lanes active in a node step on the C2 bench).
+#ifdef RT_WALK_STATS
+  long long tprev = clock64(); int phase = 12;
+#define WPHASE(ph) do { long long tn_ = clock64(); WSTAT(phase, (unsigned long long)(tn_ - tprev)); tprev = tn_; phase = (ph); } while (0)
+#else
+#define WPHASE(ph) do {} while (0)
+#endif
   for (;;) {
-    uint32_t n_walk = count_lanes(state == RT_ST_WALK);
-    if (RT_WAVE - n_walk >= refill_min || n_walk == 0) {
+    WPHASE(12);
+    if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+    if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) {  // this instance is walked
+      // TraverseTree's strict '<' in depth-first order: an equal t wins only for an earlier instance
+      if (lfound && (L.t < B.t || (L.t == B.t && W.inst < B.inst))) { B.t = L.t; B.inst = W.inst; B.mh = L; }
+      state = RT_ST_NEXT;
+    }
+    const bool walking = state == RT_ST_WALK;
+    const bool at_node = walking && ref_is_node(W.cur);
+    const uint32_t n_walk = count_lanes(walking), n_node = count_lanes(at_node), n_pend = count_lanes(walking && W.pend != 0);
+    // lanes that service can do something for (an idle lane only while unclaimed items may be left)
+    const uint32_t n_serv = count_lanes(state == RT_ST_DONE || state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
+    if (n_walk == 0 && n_serv == 0) break;
+    if (++guard > RT_WALK_GUARD) { *F.overflow = RT_WALK_ABORT; break; }
+    if (n_serv >= refill_min || n_walk == 0) {
       // ---- service: write finished rays, claim new items, enter the next mesh instance
+      WSTAT(2, 1); WSTAT(3, n_serv); WPHASE(13);
       if (state == RT_ST_DONE) {
-        Hit h;
-        finalize_hit(S, o, dir, B, h);
-        write_hit(S, P, F, Q, ray_idx, Q.q3[ray_idx], h, level);
+        write_raw(Q, ray_idx, B);
         state = RT_ST_IDLE;
       }
       if (segs_done < nseg) {
@@ -400,29 +466,26 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
           state = RT_ST_DONE;
         }
       }
-      if (count_lanes(state != RT_ST_IDLE) == 0 && segs_done >= nseg) break;
+      continue;
     }
-    // ---- BVH steps, "while-while": inner nodes until every walking lane stands at a leaf (or is done with its
-    // instance), then the leaves together — the leaf code is never issued for a wave that is mostly at inner nodes
-    // Inner nodes until (nearly) every walking lane stands at a leaf: the loop ends when fewer than RT_NODE_MIN lanes
-    // are still at inner nodes while at least as many wait at leaves; the stragglers walk on in the next round.
-    bool more = true;
-    for (;;) {
-      bool at_node = state == RT_ST_WALK && more && !(W.cur & RT_LEAF);
-      uint32_t n_node = count_lanes(at_node);
-      if (n_node == 0 || (n_node < RT_NODE_MIN && count_lanes(state == RT_ST_WALK && more && (W.cur & RT_LEAF)) >= RT_NODE_MIN)) break;
-      if (at_node) {  // (fetching inside the branch measured 10 % faster here, and 1 % slower in k_shadow_mesh)
-        float4 n0, n1, n2, n3;
-        fetch_node(S, W, true, n0, n1, n2, n3);
-        more = mesh_walk_node_closest<CNT>(W, n0, n1, n2, n3, L.t < B.t ? L.t : B.t, stk, stride, cnt);
+    if (n_node != 0 && (n_pend < RT_LEAF_MIN || n_node >= RT_WAVE / 2) && (n_node >= RT_NODE_MIN || n_pend < RT_NODE_MIN)) {
+      WSTAT(6, 1); WSTAT(7, n_node); WPHASE(14);
+      // RT_NODE_BATCH steps per decision: the wave-wide bookkeeping above costs about as much as one node step
+#pragma unroll
+      for (int k = 0; k < RT_NODE_BATCH; k++) {
+        if (k > 0 && walking && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+        if (walking && ref_is_node(W.cur)) {  // (fetching inside the branch measured 10 % faster here)
+          float4 n0, n1, n2, n3;
+          fetch_node(S, W, true, n0, n1, n2, n3);
+          mesh_walk_node<CNT, true>(W, n0, n1, n2, n3, L.t < B.t ? L.t : B.t, stk, stride, cnt);
+        }
       }
-    }
-    if (state == RT_ST_WALK && more && (W.cur & RT_LEAF))
-      more = mesh_walk_leaf_closest<CNT>(S, W, L, lfound, stk, stride, cnt);
-    if (state == RT_ST_WALK && !more) {
-      // TraverseTree's strict '<' in depth-first order: an equal t wins only for an earlier instance
-      if (lfound && (L.t < B.t || (L.t == B.t && W.inst < B.inst))) { B.t = L.t; B.inst = W.inst; B.mh = L; }
-      state = RT_ST_NEXT;
+    } else {
+      WSTAT(8, 1); WSTAT(9, n_pend); WPHASE(15);
+      if (walking && W.pend != 0) {
+        mesh_walk_leaf_closest<CNT>(S, W, W.pend, L, lfound, cnt);
+        W.pend = 0;
+      }
     }
   }
   if (CNT) {
@@ -430,6 +493,9 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
     cnt.flush_closest(F.counters);
     if (cnt.c.inst) rt_atomic_add_u64(&F.counters->mesh_inst_tests, cnt.c.inst);
     if (n_items) rt_atomic_add_u64(&F.counters->mesh_items, n_items);
+#ifdef RT_WALK_STATS
+    if (rt_lane() == 0) for (int i = 0; i < 16; i++) if (ws[i]) atomicAdd(&g_walk_stats[i], ws[i]);
+#endif
   }
 }
 
@@ -564,9 +630,24 @@ RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, G
 
     if (valid) {
       float4 q0 = Q.q0[idx], q1 = Q.q1[idx], q2 = Q.q2[idx];
-      float4 h0 = Q.h0[idx];
-      h1 = Q.h1[idx];
-      h2 = Q.h2[idx];
+      float4 h0;
+      if (reshade) {  // the hit record k_shade wrote for this entry (lights.cpp:172-183)
+        h0 = Q.h0[idx];
+        h1 = Q.h1[idx];
+        h2 = Q.h2[idx];
+      } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
+        Best B;
+        read_raw(Q, idx, B);
+        Hit h;
+        finalize_hit(S, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
+        h0 = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+        h1 = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
+        h2 = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float((h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8)));
+        if (bounce == 0 && F.hit_node && (int)m.z == P.aov_sample) {
+          F.hit_node[pixel] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
+          F.hit_face[pixel] = h.light >= 0 ? -1 : h.face;
+        }
+      }
       w = v3(q0.w, q1.w, q2.w);
       V3 pabs = v3(q2.x, q2.y, q2.z);
       V3 rdir = v3(q1.x, q1.y, q1.z);
@@ -840,8 +921,8 @@ RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_
   uint32_t rays = 0;
   const uint32_t* counts = list ? list_counts : G.counts;
   RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
-    uint32_t g = 0, j = 0;
-    bool need_mesh = false;
+    uint32_t g = RT_NONE, j = 0;
+    bool need_mesh = false, lit = false;
     if (seg_valid) {
       uint32_t e = seg_base_ + (uint32_t)(seg_e / nj);
       g = list ? list[e] : e;
@@ -852,8 +933,9 @@ RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_
       rays++;
       bool occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
       if (occ) need_mesh = false;
-      else if (!need_mesh) rt_atomic_add_u32((uint32_t*)&G.g2[g].z, 1u);
+      else if (!need_mesh) lit = true;
     }
+    run_count_add(lit, g, seg_valid ? (uint32_t*)&G.g2[g].z : nullptr);
     uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
       uint2 it;
@@ -879,12 +961,20 @@ RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   uint32_t group = 0;
   V3 o = v3(0, 0, 0), dir = v3(0, 0, 0), winv = v3(0, 0, 0);
   float tmax = 0.0f;
+  uint32_t guard = 0;
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
-  W.cur = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
-  for (;;) {
-    uint32_t n_walk = count_lanes(state == RT_ST_WALK);
-    if (RT_WAVE - n_walk >= refill_min || n_walk == 0) {  // service, batched as in k_trace_mesh
+  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  for (;;) {  // one wave-wide step per iteration, as in k_trace_mesh
+    if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+    if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) state = RT_ST_NEXT;
+    const bool walking = state == RT_ST_WALK;
+    const bool at_node = walking && ref_is_node(W.cur);
+    const uint32_t n_walk = count_lanes(walking), n_node = count_lanes(at_node), n_pend = count_lanes(walking && W.pend != 0);
+    const uint32_t n_serv = count_lanes(state == RT_ST_DONE || state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
+    if (n_walk == 0 && n_serv == 0) break;
+    if (++guard > RT_WALK_GUARD) { *F.overflow = RT_WALK_ABORT; break; }
+    if (n_serv >= refill_min || n_walk == 0) {
       if (state == RT_ST_DONE) {  // no mesh occludes the ray either: it is lit
         if (SOFT) {
           rt_atomic_add_u32((uint32_t*)&G.g2[group].z, 1u);
@@ -909,21 +999,21 @@ RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
       if (state == RT_ST_NEXT) state = mesh_walk_next<CNT>(S, o, dir, winv, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
-      if (count_lanes(state != RT_ST_IDLE) == 0 && segs_done >= nseg) break;
+      continue;
     }
-    bool occluded = false, more = true;
-    for (;;) {
-      bool at_node = state == RT_ST_WALK && more && !(W.cur & RT_LEAF);
-      uint32_t n_node = count_lanes(at_node);
-      if (n_node == 0 || (n_node < RT_NODE_MIN && count_lanes(state == RT_ST_WALK && more && (W.cur & RT_LEAF)) >= RT_NODE_MIN)) break;
-      float4 n0, n1, n2, n3;
-      fetch_node(S, W, at_node, n0, n1, n2, n3);
-      if (at_node) more = mesh_walk_node_any<CNT>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
-    }
-    if (state == RT_ST_WALK && more && (W.cur & RT_LEAF)) more = mesh_walk_leaf_any<CNT>(S, W, tmax, occluded, stk, stride, cnt);
-    if (state == RT_ST_WALK) {
+    if (n_node != 0 && (n_pend < RT_LEAF_MIN || n_node >= RT_WAVE / 2) && (n_node >= RT_NODE_MIN || n_pend < RT_NODE_MIN)) {
+#pragma unroll
+      for (int k = 0; k < RT_NODE_BATCH; k++) {
+        if (k > 0 && walking && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+        const bool an = walking && ref_is_node(W.cur);
+        float4 n0, n1, n2, n3;
+        fetch_node(S, W, an, n0, n1, n2, n3);
+        if (an) mesh_walk_node<CNT, false>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+      }
+    } else if (walking && W.pend != 0) {
+      bool occluded = mesh_walk_leaf_any<CNT>(S, W, W.pend, tmax, cnt);
+      W.pend = 0;
       if (occluded) state = RT_ST_IDLE;
-      else if (!more) state = RT_ST_NEXT;
     }
   }
   if (CNT) cnt.flush(F.counters);

@@ -42,6 +42,10 @@
 // persistent grid sizes
 #define LAUNCH(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
 #define LAUNCH_T(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks_trace, __VA_ARGS__)
+#ifndef RT_P1_BLOCKS
+#define RT_P1_BLOCKS max_blocks   // first-phase trace kernels (instance table only, no BVH stack): streaming grid
+#endif
+#define LAUNCH_P1(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->RT_P1_BLOCKS, __VA_ARGS__)
 #else
 #define LAUNCH(kern, n_items, ...) kern(__VA_ARGS__)
 #define LAUNCH_T(kern, n_items, ...) kern(__VA_ARGS__)
@@ -968,6 +972,8 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q1 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q2 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.q3 = (uint4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.r0 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 4, &p))) return rc; q.rf = (uint32_t*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h0 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h1 = (float4*)p;
     if ((rc = alloc_dev(ctx, ctx->frame_mem, qcap * 16, &p))) return rc; q.h2 = (float4*)p;
@@ -1079,7 +1085,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     {
       MeshQ MQ = meshq(ctx->MQ, CNT_MQ, CUR_MQ);
       Timer t(ctx, RT_K_TRACE_CLOSEST);
-      LAUNCH_T(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, MQ, lvl);
+      LAUNCH_P1(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, MQ, lvl);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
       if (meshes) {
         Timer t2(ctx, RT_K_TRACE_MESH);
@@ -1096,7 +1102,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       Timer t(ctx, RT_K_SHADOW);
       MeshQ MH = meshq(ctx->MH, CNT_MH, CUR_MH);
       uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
-      LAUNCH_T(k_shadow_hard<CNT>, gh_ub, ctx->ds, P, F, GH, MH);
+      LAUNCH_P1(k_shadow_hard<CNT>, gh_ub, ctx->ds, P, F, GH, MH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
       if (meshes) {
         Timer t2(ctx, RT_K_SHADOW_MESH);
@@ -1109,13 +1115,13 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
       MeshQ MS1 = meshq(ctx->MS, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
-      LAUNCH_T(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+      LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
                (uint32_t)P.shadow_min, MS1);
       if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
         uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
-        LAUNCH_T(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
+        LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
                  (uint32_t)P.shadow_min, nr, MS2);
         if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
@@ -1185,7 +1191,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   const double fworst[7] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
                             meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0};
   auto per_path_bytes = [&](const double* f) {
-    return 2.0 * 112 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
+    return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
   };
   // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
   // traversal kernels, and HBM is 288 GB
@@ -1267,6 +1273,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     HIP_TRY(hipMemcpyAsync(raw.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    if (raw[CNT_OVERFLOW] == RT_WALK_ABORT) return fail(ctx, RT_ERR_DEVICE, "a traversal wave exceeded its step limit (internal error)");
     overflowed = raw[CNT_OVERFLOW] != 0;
     if (ctx->profile_on) {
       for (size_t s = 0; s < counts.size(); s++) {
@@ -1615,6 +1622,20 @@ int rt_counters_get(rt_context* ctx, rt_counters* out) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out, ctx->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost));
   out->paths += ctx->host_paths;
+#ifdef RT_WALK_STATS
+  {
+    unsigned long long ws[16];
+    if (hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_walk_stats), sizeof ws) == hipSuccess) {
+      std::fprintf(stderr, "walk stats: outer %llu (walk lanes %.1f) | service %llu (done %.1f idle %.1f next %.1f) | node iters %llu (lanes %.1f) | leaf phases %llu (lanes %.1f) | tri iters %llu (lanes %.1f)\n",
+                   ws[0], (double)ws[1] / (double)(ws[0] ? ws[0] : 1), ws[2], (double)ws[3] / (double)(ws[2] ? ws[2] : 1), (double)ws[4] / (double)(ws[2] ? ws[2] : 1),
+                   (double)ws[5] / (double)(ws[2] ? ws[2] : 1), ws[6], (double)ws[7] / (double)(ws[6] ? ws[6] : 1), ws[8], (double)ws[9] / (double)(ws[8] ? ws[8] : 1), ws[10],
+                   (double)ws[11] / (double)(ws[10] ? ws[10] : 1));
+      double tt = (double)(ws[12] + ws[13] + ws[14] + ws[15]);
+      std::fprintf(stderr, "walk cycles: classify %.1f%% service %.1f%% node %.1f%% leaf %.1f%% (total %.3g wave-cycles)\n", 100.0 * ws[12] / tt, 100.0 * ws[13] / tt,
+                   100.0 * ws[14] / tt, 100.0 * ws[15] / tt, tt);
+    }
+  }
+#endif
   return RT_OK;
 }
 int rt_profile_enable(rt_context* ctx, int enable) {
