@@ -42,13 +42,12 @@
 // persistent grid sizes
 #define LAUNCH(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
 #define LAUNCH_T(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks_trace, __VA_ARGS__)
-#ifndef RT_P1_BLOCKS
-#define RT_P1_BLOCKS max_blocks   // first-phase trace kernels (instance table only, no BVH stack): streaming grid
-#endif
-#define LAUNCH_P1(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->RT_P1_BLOCKS, __VA_ARGS__)
+// first-phase trace kernels (instance table only, no BVH stack): streaming grid (measured: k_trace_closest 2.18 -> 1.92 ms)
+#define LAUNCH_P1(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
 #else
 #define LAUNCH(kern, n_items, ...) kern(__VA_ARGS__)
 #define LAUNCH_T(kern, n_items, ...) kern(__VA_ARGS__)
+#define LAUNCH_P1(kern, n_items, ...) kern(__VA_ARGS__)
 #endif
 
 #ifndef RT_BLOCKS_PER_CU
