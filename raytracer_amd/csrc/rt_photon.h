@@ -168,49 +168,119 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 }
 
 // ------------------------------------------------------------------------------------------------ gather
-struct HeapMem {     // per-lane views: entry i of this lane is at [i * stride]
-  float* d2;
-  uint32_t* idx;
-  uint32_t* walk;
+// PhotonMap::IrradianceEstimate<true, k, CONSTANT> (photonmap.h:268-309) over LocatePhotons<true> (:339-414).
+//
+// What the reference computes.  Call a photon ELIGIBLE for a query when its squared distance and (for ellipticity != 1)
+// its ellipsoidal squared distance d' are below radius^2 and its direction faces the surface (dir . n < 0).
+// LocatePhotons keeps the first k eligible photons it visits, heapifies them, and from the (k+1)-th on replaces the
+// heap's root whenever a photon is closer than the current bound.  The bound (dist2[0]) stays radius^2 until that first
+// replacement (:375-411), so the first replacement evicts the root WHATEVER the newcomer's distance.  Consequences:
+//   |U| <= k                 the result is all of U, area = pi * radius^2;
+//   otherwise                the result is the k nearest of U and the bound is the k-th smallest d', EXCEPT when the
+//                            first k eligible photons in visiting order are exactly the k nearest: then the (k+1)-th
+//                            visited (farther than all of them) evicts the k-th nearest, and the result is the k-1
+//                            nearest plus the (k+1)-th nearest, with the bound at the (k+1)-th smallest d'.
+// The device computes exactly that set without the per-query heap (k = 128 entries x 8 bytes per lane is what capped the
+// heap kernel at two waves per CU and 8 G node visits/s): the (k+1)-th smallest d' is found by counting eligible
+// photons below 16 thresholds per fixed-radius walk of the same kd-tree (the bracket narrows 16x per walk, starting
+// with radius^2 / 4), the last walk sums the powers below the bracket and keeps the bracket's <= 16 photons sorted in
+// registers, and a walk in the reference's visiting order that stops at the first eligible photon beyond the k-th
+// distance decides the exception.  Per-lane memory is the kd walk stack only.  The photon SET is the reference's (equal
+// d' values among different photons are resolved by visiting order here and by heap history there); the power sum runs
+// in visiting order instead of heap order, i.e. irradiance agrees to float-sum reordering (tests: 2e-5 relative).
+struct HeapMem {     // per-lane views of the kd walk stack: entry i of this lane is at [i * stride]
+  uint32_t* walk;    // node index << 2 | state
+  float* wdist;      // signed distance of the query to that node's splitting plane
   uint32_t stride;
 };
 
-// PhotonMap::IrradianceEstimate<true, k, CONSTANT> (photonmap.h:268-309) with LocatePhotons<true> (:339-414)
-// unrolled into an explicit walk: state 0 = entering a node, 1 = first child done, 2 = second child done.
-RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, float ellipticity, int k, const HeapMem& hm,
-                          uint32_t& visits) {
-  V3 irrad = v3(0, 0, 0);
-  if (M.stored == 0) return irrad;
+RT_DEV V3 photon_power(float4 pa, float4 pb) {  // PhotonData::GetPower = Color24::ToColor() * power
+  uint32_t bits = __float_as_uint(pb.w);
+  return v3((float)(bits & 255u) / 255.0f, (float)((bits >> 8) & 255u) / 255.0f, (float)((bits >> 16) & 255u) / 255.0f) * pa.w;
+}
+
+// Visits, in LocatePhotons' order, every photon of the kd-tree that is eligible under the FIXED squared radius `bound`
+// and calls f(d', index, pa, pb); f returns true to stop the walk.  One `visits` per node entered (photonmap.h:340).
+template <class F>
+RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
   const uint32_t hs = hm.stride;
-  float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
-  int found = 0;
-  float bound = radius * radius;  // np.dist2[0]
   int sp = 0;
-  uint32_t index = 1, state = 0;
+  uint32_t index = 1;
+  bool enter = true;
   for (;;) {
-    if (state == 0) visits++;  // one LocatePhotons call per node entered
     float4 pa = M.ph[2 * (size_t)index];
     float4 pb = M.ph[2 * (size_t)index + 1];
-    int axis = (int)((__float_as_uint(pb.w) >> 24) & 3u);
-    bool process = true;
-    if ((int)index < M.half && state < 2) {
+    if (enter) {
+      visits++;
+      if ((int)index < M.half) {  // internal node: nearer child first (photonmap.h:346-355)
+        int axis = (int)((__float_as_uint(pb.w) >> 24) & 3u);
+        float pc = axis == 0 ? pa.x : (axis == 1 ? pa.y : pa.z);
+        float qc = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
+        float dist = qc - pc;
+        hm.walk[sp * hs] = (index << 2) | 1u;
+        hm.wdist[sp * hs] = dist;
+        sp++;
+        index = dist > 0.0f ? 2 * index + 1 : 2 * index;
+        continue;
+      }
+    }
+    {  // photonmap.h:357-373
+      V3 dif = v3(pa.x, pa.y, pa.z) - pos;
+      float dist2 = dot(dif, dif);
+      if (dist2 < bound) {
+        V3 dir = v3(pb.x, pb.y, pb.z);
+        bool keep = !(dot(dir, normal) >= 0.0f);
+        if (keep && normScale > 0.0f) {
+          float perp = dot(dif, normal);
+          dif = dif + normal * (perp * normScale);
+          dist2 = dot(dif, dif);
+          if (dist2 >= bound) keep = false;
+        }
+        if (keep && f(dist2, index, pa, pb)) return;
+      }
+    }
+    for (;;) {  // back up: second child if the splitting plane is within the radius, then the node's own photon
+      if (sp == 0) return;
+      uint32_t w = hm.walk[(sp - 1) * hs];
+      index = w >> 2;
+      if ((w & 3u) == 1u) {
+        float dist = hm.wdist[(sp - 1) * hs];
+        if (dist * dist < bound) {
+          hm.walk[(sp - 1) * hs] = (index << 2) | 2u;
+          index = dist > 0.0f ? 2 * index : 2 * index + 1;
+          enter = true;
+          break;
+        }
+      }
+      sp--;
+      enter = false;  // process photon `index` itself
+      break;
+    }
+  }
+}
+
+// The same set of photons in pre-order (node, nearer child, farther child): with a FIXED radius the decision to enter
+// the farther child does not depend on what the nearer subtree held, so a node is fetched once and the stack holds
+// nothing but the farther children still to enter.  For the counting / collecting walks, whose results do not depend on
+// the order.
+template <class F>
+RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
+  const uint32_t hs = hm.stride;
+  int sp = 0;
+  uint32_t index = 1;
+  for (;;) {
+    float4 pa = M.ph[2 * (size_t)index];
+    float4 pb = M.ph[2 * (size_t)index + 1];
+    visits++;
+    uint32_t next = 0;
+    if ((int)index < M.half) {
+      int axis = (int)((__float_as_uint(pb.w) >> 24) & 3u);
       float pc = axis == 0 ? pa.x : (axis == 1 ? pa.y : pa.z);
       float qc = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
       float dist = qc - pc;
-      uint32_t first = dist > 0.0f ? 2 * index + 1 : 2 * index;
-      uint32_t second = dist > 0.0f ? 2 * index : 2 * index + 1;
-      if (state == 0) {
-        hm.walk[(sp++) * hs] = (index << 2) | 1u;
-        index = first; state = 0;
-        process = false;
-      } else if (dist * dist < bound) {
-        hm.walk[(sp++) * hs] = (index << 2) | 2u;
-        index = second; state = 0;
-        process = false;
-      }
+      next = dist > 0.0f ? 2 * index + 1 : 2 * index;
+      if (dist * dist < bound) hm.walk[(sp++) * hs] = next ^ 1u;  // the sibling
     }
-    if (!process) continue;
-    // photonmap.h:366-413
     V3 dif = v3(pa.x, pa.y, pa.z) - pos;
     float dist2 = dot(dif, dif);
     if (dist2 < bound) {
@@ -222,102 +292,178 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
         dist2 = dot(dif, dif);
         if (dist2 >= bound) keep = false;
       }
-      if (keep) {
-        if (found < k) {
-          found++;
-          hm.d2[found * hs] = dist2;
-          hm.idx[found * hs] = index;
-          if (found == k) {  // build the max-heap
-            int half_found = found >> 1;
-            for (int kk = half_found; kk >= 1; kk--) {
-              int parent = kk;
-              uint32_t tp = hm.idx[kk * hs];
-              float td2 = hm.d2[kk * hs];
-              while (parent <= half_found) {
-                int j = parent + parent;
-                if (j < found && hm.d2[j * hs] < hm.d2[(j + 1) * hs]) j++;
-                float dj = hm.d2[j * hs];
-                if (td2 >= dj) break;
-                hm.d2[parent * hs] = dj;
-                hm.idx[parent * hs] = hm.idx[j * hs];
-                parent = j;
-              }
-              hm.idx[parent * hs] = tp;
-              hm.d2[parent * hs] = td2;
-            }
-          }
-        } else {
-          int parent = 1;
-          int j = 2;
-          while (j <= found) {
-            if (j < found && hm.d2[j * hs] < hm.d2[(j + 1) * hs]) j++;
-            float dj = hm.d2[j * hs];
-            if (dist2 > dj) break;
-            hm.d2[parent * hs] = dj;
-            hm.idx[parent * hs] = hm.idx[j * hs];
-            parent = j;
-            j <<= 1;
-          }
-          hm.idx[parent * hs] = index;
-          hm.d2[parent * hs] = dist2;
-          bound = hm.d2[1 * hs];
-        }
+      if (keep) f(dist2, index, pa, pb);
+    }
+    if (next == 0) {
+      if (sp == 0) return;
+      next = hm.walk[(--sp) * hs];
+    }
+    index = next;
+  }
+}
+
+#ifndef RT_TEST_NO_EVICT_RULE
+#define RT_TEST_NO_EVICT_RULE 0   // tests build a variant with 1 to prove that the exception below is exercised
+#endif
+#define RT_SEL 16   // thresholds per counting walk = photons kept sorted by the collecting walk
+// `guess`: in, a squared radius expected to hold about k + 1 eligible photons (<= 0: none yet); out, what this query
+// needed.  Only the number of walks depends on it, never the result.
+RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, float ellipticity, int k, const HeapMem& hm,
+                          uint32_t& visits, float& guess) {
+  V3 irrad = v3(0, 0, 0);
+  if (M.stored == 0) return irrad;
+  const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
+  const float r2 = radius * radius;
+  const uint32_t K = (uint32_t)k;
+  // ---- bracket [lo, hi) of the (k+1)-th smallest d': C(lo) <= k and C(hi) >= k + 1, C(t) = #{eligible, d' < t}
+  float lo = 0.0f, hi = guess > 0.0f && guess < r2 ? guess : r2 * 0.25f;
+  uint32_t c_lo = 0, c_hi = 0;
+  bool hi_known = false, all = false;
+  for (int iter = 0; iter < 12; iter++) {
+    if (hi_known && c_hi - c_lo <= RT_SEL) break;
+    float t[RT_SEL];
+    uint32_t c[RT_SEL];
+    const float step = (hi - lo) * (1.0f / RT_SEL);
+#pragma unroll
+    for (int i = 0; i < RT_SEL; i++) { t[i] = lo + step * (float)(i + 1); c[i] = 0; }
+    t[RT_SEL - 1] = hi;
+    uint32_t below = 0;
+    photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t, float4, float4) {
+      if (d2 < lo) { below++; return; }
+#pragma unroll
+      for (int i = 0; i < RT_SEL; i++) c[i] += d2 < t[i] ? 1u : 0u;
+    });
+    c_lo = below;
+    c_hi = below + c[RT_SEL - 1];
+    hi_known = true;
+    if (c_hi < K + 1) {
+      if (hi == r2) { all = true; lo = r2; break; }  // at most k eligible photons in all: the result is all of them
+      if (c_hi <= K) { lo = hi; c_lo = c_hi; }
+      // too small: grow by the areal extrapolation of the count (photons lie on surfaces), with a margin
+      float grow = c_hi >= 8 ? 1.3f * (float)(K + 1) / (float)c_hi : 4.0f;
+      hi = hi * (grow > 1.25f ? grow : 1.25f);
+      if (!(hi < 0.8f * r2)) hi = r2;
+      hi_known = false;
+      continue;
+    }
+    float nlo = lo, nhi = hi;
+    uint32_t nclo = c_lo, nchi = c_hi;
+#pragma unroll
+    for (int i = RT_SEL - 2; i >= 0; i--)
+      if (below + c[i] >= K + 1 && t[i] < hi) { nhi = t[i]; nchi = below + c[i]; }
+#pragma unroll
+    for (int i = 0; i < RT_SEL - 1; i++)
+      if (below + c[i] <= K && t[i] < nhi) { nlo = t[i]; nclo = below + c[i]; }
+    if (nlo == lo && nhi == hi) break;     // thresholds no longer separate anything (equal d' values): collect as is
+    lo = nlo; hi = nhi; c_lo = nclo; c_hi = nchi;
+  }
+  // ---- collect: powers below the bracket, the bracket's photons sorted by d' (ties in visiting order)
+  float ed[RT_SEL];
+  uint32_t ei[RT_SEL];
+#pragma unroll
+  for (int i = 0; i < RT_SEL; i++) { ed[i] = RT_BIG; ei[i] = 0; }
+  V3 sum = v3(0, 0, 0);
+  uint32_t n_below = 0, n_all = 0;
+  float max_d = -1.0f;       // largest d' among the photons summed so far, and which photon that is
+  uint32_t max_i = 0;
+  photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t index, float4 pa, float4 pb) {
+    n_all++;
+    if (d2 < lo) {
+      n_below++;
+      sum = sum + photon_power(pa, pb);
+      if (d2 > max_d) { max_d = d2; max_i = index; }
+      return;
+    }
+    float nd = d2;
+    uint32_t ni = index;
+#pragma unroll
+    for (int i = 0; i < RT_SEL; i++) {
+      bool sw = nd < ed[i];
+      float td = ed[i]; uint32_t ti = ei[i];
+      ed[i] = sw ? nd : td; ei[i] = sw ? ni : ti;
+      nd = sw ? td : nd; ni = sw ? ti : ni;
+    }
+  });
+  if (n_all == 0) return irrad;
+  float bound;
+  if (all) {  // |U| <= k: everything was summed (lo = radius^2), area from the search radius (dist2[0] never changes)
+    bound = r2;
+  } else {
+    // ranks n_below + 1 .. in the bracket list; rank k is the last one kept, rank k + 1 decides the exception
+    const uint32_t j_k = K - 1 - n_below, j_k1 = K - n_below;  // list positions of the k-th and (k+1)-th nearest
+    float d_k = max_d, d_k1 = RT_BIG;
+    uint32_t i_k = max_i, i_k1 = 0;
+    bool have_k1 = false;
+#pragma unroll
+    for (int i = 0; i < RT_SEL; i++) {
+      if ((uint32_t)i <= j_k && n_below < K && ed[i] < RT_BIG) {
+        sum = sum + photon_power(M.ph[2 * (size_t)ei[i]], M.ph[2 * (size_t)ei[i] + 1]);
+        if ((uint32_t)i == j_k) { d_k = ed[i]; i_k = ei[i]; }
+      }
+      if ((uint32_t)i == j_k1 && ed[i] < RT_BIG) { d_k1 = ed[i]; i_k1 = ei[i]; have_k1 = true; }
+    }
+    bound = d_k;
+    if (have_k1) {
+      // the exception: the first k eligible photons in visiting order are the k nearest (none beyond the k-th distance)
+      uint32_t seen = 0;
+      bool beyond = false;
+      photon_walk(M, pos, normal, normScale, r2, hm, visits, [&](float d2, uint32_t, float4, float4) {
+        if (d2 > d_k) { beyond = true; return true; }
+        return ++seen == K;
+      });
+      if (!beyond && seen == K && !RT_TEST_NO_EVICT_RULE) {
+        sum = sum - photon_power(M.ph[2 * (size_t)i_k], M.ph[2 * (size_t)i_k + 1]);
+        sum = sum + photon_power(M.ph[2 * (size_t)i_k1], M.ph[2 * (size_t)i_k1 + 1]);
+        bound = d_k1;
       }
     }
-    if (sp == 0) break;
-    uint32_t w = hm.walk[(--sp) * hs];
-    index = w >> 2; state = w & 3u;
   }
-  for (int i = 1; i <= found; i++) {  // photonmap.h:289-297, GetPower = Color24::ToColor() * power
-    uint32_t id = hm.idx[i * hs];
-    float4 pa = M.ph[2 * (size_t)id];
-    uint32_t bits = __float_as_uint(M.ph[2 * (size_t)id + 1].w);
-    V3 col = v3((float)(bits & 255u) / 255.0f, (float)((bits >> 8) & 255u) / 255.0f, (float)((bits >> 16) & 255u) / 255.0f);
-    irrad = irrad + col * pa.w;
-  }
-  if (found > 0) {
-    float area = RT_PI_F * bound;
-    if (area > 0.0f) {
-      float one_over_area = 1.0f / area;
-      irrad = irrad * one_over_area;
-    }
-  }
-  return irrad;
+  guess = all ? r2 : bound * 1.25f;
+  float area = RT_PI_F * bound;
+  if (area > 0.0f) sum = sum * (1.0f / area);
+  return sum;
 }
 
 #ifndef RT_EMU
 #define RT_GATHER_BLOCK 64
-// dynamic LDS: d2[(k+1)][64], idx[(k+1)][64], walk[RT_PHOTON_TSTACK][64]
-#define RT_HEAP_DECL(k_)                                                                  \
+// dynamic LDS: walk[depth][64], wdist[depth][64]
+#define RT_HEAP_DECL(depth_)                                                               \
   extern __shared__ uint32_t s_heap_raw[];                                                 \
   HeapMem hm;                                                                              \
   hm.stride = RT_GATHER_BLOCK;                                                             \
-  hm.d2 = (float*)s_heap_raw + threadIdx.x;                                                \
-  hm.idx = s_heap_raw + (size_t)((k_) + 1) * RT_GATHER_BLOCK + threadIdx.x;                \
-  hm.walk = s_heap_raw + 2 * (size_t)((k_) + 1) * RT_GATHER_BLOCK + threadIdx.x;
-static inline size_t photon_heap_bytes(int k) { return ((size_t)2 * (k + 1) + RT_PHOTON_TSTACK) * RT_GATHER_BLOCK * 4; }
+  hm.walk = s_heap_raw + threadIdx.x;                                                      \
+  hm.wdist = (float*)s_heap_raw + (size_t)(depth_) * RT_GATHER_BLOCK + threadIdx.x;
+static inline size_t photon_heap_bytes(int depth) { return (size_t)2 * depth * RT_GATHER_BLOCK * 4; }
 #else
 #define RT_GATHER_BLOCK 1
-#define RT_HEAP_DECL(k_)                                                                   \
-  static float e_d2[RT_PHOTON_MAX_K + 1];                                                  \
-  static uint32_t e_idx[RT_PHOTON_MAX_K + 1], e_walk[RT_PHOTON_TSTACK];                    \
+#define RT_HEAP_DECL(depth_)                                                               \
+  static uint32_t e_walk[RT_PHOTON_TSTACK];                                                \
+  static float e_wdist[RT_PHOTON_TSTACK];                                                  \
   HeapMem hm;                                                                              \
-  hm.stride = 1; hm.d2 = e_d2; hm.idx = e_idx; hm.walk = e_walk;
+  hm.stride = 1; hm.walk = e_walk; hm.wdist = e_wdist;
 static inline size_t photon_heap_bytes(int) { return 0; }
 #endif
+// levels of a heap-ordered kd-tree over n photons (+1 spare): the walk stack holds one entry per level
+static inline int photon_tree_depth(int n) {
+  int d = 1;
+  while ((1ll << d) <= (long long)n) d++;
+  return d + 1;
+}
 
 struct GatherP {
   DPhotonMap map[2];
   float radius;
   float ellipticity[2];
   int32_t k;
+  int32_t depth;   // walk stack entries per lane
 };
 
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
 template <bool CNT>
 RT_KERNEL(k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
-  RT_HEAP_DECL(G.k)
+  RT_HEAP_DECL(G.depth)
   uint32_t visits = 0, gathers = 0;
+  float guess[2] = {0.0f, 0.0f};  // per map: the squared radius the lane's previous lookup needed
   RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
     if (!seg_valid) continue;
     uint32_t g = seg_base_ + (uint32_t)seg_e;
@@ -325,7 +471,9 @@ RT_KERNEL(k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
     uint32_t which = __float_as_uint(b.w) & 1u;
     const DPhotonMap& M = which ? G.map[1] : G.map[0];
     if (M.stored > 0) gathers++;
-    V3 E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, which ? G.ellipticity[1] : G.ellipticity[0], G.k, hm, visits);
+    float gs = which ? guess[1] : guess[0];
+    V3 E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, which ? G.ellipticity[1] : G.ellipticity[0], G.k, hm, visits, gs);
+    if (which) guess[1] = gs; else guess[0] = gs;
     add_radiance(F, __float_as_uint(a.w), v3(c.x, c.y, c.z) * E);
   RT_SEG_END
   if (CNT) {
@@ -336,12 +484,13 @@ RT_KERNEL(k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
 
 // batched PhotonMap::EstimateIrradiance for the C-ABI (rt_photon_gather)
 RT_KERNEL(k_api_photon_gather, DPhotonMap M, const float* P, const float* N, uint32_t n, float radius, float ellipticity, int k,
-          float* out) {
-  RT_HEAP_DECL(k)
+          int depth, float* out) {
+  RT_HEAP_DECL(depth)
   uint32_t visits = 0;
+  float guess = 0.0f;
   for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) {
     V3 E = photon_estimate(M, v3(P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2]),
-                           v3(N[3 * (size_t)i], N[3 * (size_t)i + 1], N[3 * (size_t)i + 2]), radius, ellipticity, k, hm, visits);
+                           v3(N[3 * (size_t)i], N[3 * (size_t)i + 1], N[3 * (size_t)i + 2]), radius, ellipticity, k, hm, visits, guess);
     out[3 * (size_t)i] = E.x; out[3 * (size_t)i + 1] = E.y; out[3 * (size_t)i + 2] = E.z;
   }
 }

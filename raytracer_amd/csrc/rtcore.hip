@@ -878,17 +878,17 @@ int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* pho
 }
 
 #ifndef RT_EMU
-#define LAUNCH_GATHER(kern, n_items, k_, ...)                                                              \
+#define LAUNCH_GATHER(kern, n_items, depth_, ...)                                                          \
   do {                                                                                                     \
     unsigned long long nb_ = ((unsigned long long)(n_items) + RT_GATHER_BLOCK - 1) / RT_GATHER_BLOCK;      \
     if (nb_ < 1) nb_ = 1;                                                                                  \
     if (nb_ > (unsigned long long)ctx->max_blocks_trace * 4) nb_ = (unsigned long long)ctx->max_blocks_trace * 4;\
-    size_t lds_ = photon_heap_bytes(k_);                                                                   \
+    size_t lds_ = photon_heap_bytes(depth_);                                                                 \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);   \
     hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_GATHER_BLOCK), lds_, ctx->stream, __VA_ARGS__);  \
   } while (0)
 #else
-#define LAUNCH_GATHER(kern, n_items, k_, ...) kern(__VA_ARGS__)
+#define LAUNCH_GATHER(kern, n_items, depth_, ...) kern(__VA_ARGS__)
 #endif
 
 int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius,
@@ -908,8 +908,9 @@ int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* 
   hipError_t e = hipMemcpyAsync(d_p, P, n * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_n, N, n * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    LAUNCH_GATHER(k_api_photon_gather, n, k, photon_dmap(ps, which), (const float*)d_p, (const float*)d_n, (uint32_t)n, radius,
-                  ellipticity, k, (float*)d_o);
+    const int depth = photon_tree_depth(ps.count[which]);
+    LAUNCH_GATHER(k_api_photon_gather, n, depth, photon_dmap(ps, which), (const float*)d_p, (const float*)d_n, (uint32_t)n, radius,
+                  ellipticity, k, depth, (float*)d_o);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(irradiance, d_o, n * 12, hipMemcpyDeviceToHost, ctx->stream);
@@ -928,7 +929,8 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.ellipticity[0] = RP.ellipticity_global;
   G.ellipticity[1] = RP.ellipticity_caustic;
   G.k = RP.photon_k;
-  LAUNCH_GATHER(k_photon_gather<CNT>, upper, RP.photon_k, G, F, GQ);
+  G.depth = photon_tree_depth(std::max(ctx->photons.count[0], ctx->photons.count[1]));
+  LAUNCH_GATHER(k_photon_gather<CNT>, upper, G.depth, G, F, GQ);
 }
 
 // Queue capacities are entries per camera sample of a pass, by kind: f[0] ray queue (levels >= 1), f[1] hard-shadow

@@ -9,7 +9,7 @@ from raytracer_amd import Scene
 pytestmark = pytest.mark.gpu
 
 
-def test_gather_bit_exact(gpu_renderer):
+def test_gather_matches_reference_heap(gpu_renderer):
     pc.check_gather_matches_kdtree_walk(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000,
                                         n_queries=4096)
 
