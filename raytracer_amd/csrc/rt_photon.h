@@ -500,6 +500,7 @@ struct PhotonState {
   bool built = false;
   uint32_t key[8] = {0};   // parameters the maps were built with
   void* d_map[2] = {nullptr, nullptr};
+  size_t d_cap[2] = {0, 0};   // photons the device buffers hold
   int32_t count[2] = {0, 0};
   uint32_t emitted = 0;
   std::vector<rt_photon> raw[2];  // insertion order, powers scaled (what GetPhotonMap()'s array holds before balancing)
@@ -509,6 +510,7 @@ static inline void photon_state_free(PhotonState& s) {
   for (int i = 0; i < 2; i++) {
     if (s.d_map[i]) (void)hipFree(s.d_map[i]);
     s.d_map[i] = nullptr;
+    s.d_cap[i] = 0;
     s.count[i] = 0;
     s.raw[i].clear();
   }

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -657,8 +658,10 @@ void collect_profile(rt_context* ctx, const std::vector<uint32_t>& counts) {
 
 // PhotonMap::BalanceSegment (photonmap.h:202-264) on the host, as the reference does it: the left-balanced kd-tree in
 // heap order.  `ph` is 1-based (slot 0 unused), `bal` receives the tree.
+// The two sub-segments are disjoint ranges of `ph` and disjoint subtrees of `bal`, so the top `par` levels of the
+// recursion run their left halves on threads of their own (the result does not depend on it).
 void photon_balance_segment(std::vector<rt_photon>& ph, std::vector<rt_photon>& bal, const float* bmin, const float* bmax,
-                            int index, int start, int end) {
+                            int index, int start, int end, int par = 0) {
   int median = 1;
   while ((4 * median) <= (end - start + 1)) median += median;
   if ((3 * median) <= (end - start + 1)) {
@@ -691,11 +694,15 @@ void photon_balance_segment(std::vector<rt_photon>& ph, std::vector<rt_photon>& 
   }
   bal[index] = ph[median];
   bal[index].plane = (uint8_t)((bal[index].plane & 0x8) | (axis & 0x3));
+  std::thread left_worker;
+  float tmax[3] = {bmax[0], bmax[1], bmax[2]};
   if (median > start) {
     if (start < median - 1) {
-      float tmax[3] = {bmax[0], bmax[1], bmax[2]};
       tmax[axis] = bal[index].position[axis];
-      photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1);
+      if (par > 0 && median - start > 4096)
+        left_worker = std::thread([&, index, start, median, par] { photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1, par - 1); });
+      else
+        photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1, 0);
     } else {
       bal[2 * index] = ph[start];
     }
@@ -704,11 +711,12 @@ void photon_balance_segment(std::vector<rt_photon>& ph, std::vector<rt_photon>& 
     if (median + 1 < end) {
       float tmin[3] = {bmin[0], bmin[1], bmin[2]};
       tmin[axis] = bal[index].position[axis];
-      photon_balance_segment(ph, bal, tmin, bmax, 2 * index + 1, median + 1, end);
+      photon_balance_segment(ph, bal, tmin, bmax, 2 * index + 1, median + 1, end, par > 0 ? par - 1 : 0);
     } else {
       bal[2 * index + 1] = ph[end];
     }
   }
+  if (left_worker.joinable()) left_worker.join();
 }
 
 // PhotonMap::PrepareForIrradianceEstimation (photonmap.h:176-198).  raw = photons in insertion order.
@@ -725,18 +733,24 @@ void photon_balance(const std::vector<rt_photon>& raw, std::vector<rt_photon>& b
       if (bmin[a] > ph[i].position[a]) bmin[a] = ph[i].position[a];
       if (bmax[a] < ph[i].position[a]) bmax[a] = ph[i].position[a];
     }
-  photon_balance_segment(ph, bal, bmin, bmax, 1, 1, stored);
+  photon_balance_segment(ph, bal, bmin, bmax, 1, 1, stored, stored >= 16384 ? 3 : 0);
 }
 
-int photon_upload_map(PhotonState& ps, rt_context* ctx, int which, const std::vector<rt_photon>& raw) {
-  std::vector<rt_photon> bal;
-  photon_balance(raw, bal);
-  if (ps.d_map[which]) { (void)hipFree(ps.d_map[which]); ps.d_map[which] = nullptr; }
-  HIP_TRY(hipMalloc(&ps.d_map[which], bal.size() * sizeof(rt_photon)));
+int photon_upload_balanced(PhotonState& ps, rt_context* ctx, int which, std::vector<rt_photon>& raw, const std::vector<rt_photon>& bal) {
+  if (!ps.d_map[which] || ps.d_cap[which] < bal.size()) {
+    if (ps.d_map[which]) { (void)hipFree(ps.d_map[which]); ps.d_map[which] = nullptr; }
+    HIP_TRY(hipMalloc(&ps.d_map[which], bal.size() * sizeof(rt_photon)));
+    ps.d_cap[which] = bal.size();
+  }
   HIP_TRY(hipMemcpy(ps.d_map[which], bal.data(), bal.size() * sizeof(rt_photon), hipMemcpyHostToDevice));
   ps.count[which] = (int32_t)raw.size();
-  ps.raw[which] = raw;
+  ps.raw[which].swap(raw);
   return RT_OK;
+}
+int photon_upload_map(PhotonState& ps, rt_context* ctx, int which, std::vector<rt_photon>& raw) {
+  std::vector<rt_photon> bal;
+  photon_balance(raw, bal);
+  return photon_upload_balanced(ps, ctx, which, raw, bal);
 }
 
 DPhotonMap photon_dmap(const PhotonState& ps, int which) {
@@ -762,9 +776,15 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
     if (ctx->lights[l].kind == RT_LIGHT_POINT) plights.push_back((int32_t)l);  // IsPhotonSource, lights.h:63
 
   std::vector<rt_photon> kept[2];
+  kept[0].reserve(n);
+  kept[1].reserve(n);
   uint32_t emitted = 0;
+  const bool timing = std::getenv("RT_TIMING") != nullptr;   // developer aid: host-side phases of the build on stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_start = now(), t_kernel = 0, t_copy = 0, t_sort = 0;
+  int n_batches = 0;
   if (!plights.empty()) {
-    uint32_t batch = 1u << 16;
+    uint32_t batch = 1u << 16, cap_batch = 1u << 21;
     std::vector<DevMem> tmp;
     int rc = RT_OK;
     struct Cleanup { std::vector<DevMem>& t; ~Cleanup() { free_pool(t); } } cleanup{tmp};
@@ -781,6 +801,8 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
     std::vector<rt_photon> h_rec;
     std::vector<uint64_t> h_key;
     std::vector<uint32_t> order;
+    std::vector<uint64_t> sorted;
+    if (cap > (1u << 24) || max_b > 255) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_max_bounces must be <= 255");  // packed sort word
     while ((kept[0].size() < n || kept[1].size() < n) && (long long)emitted < limit) {
       uint32_t count = (uint32_t)std::min<long long>(batch, limit - emitted);
       PhotonTraceP PP;
@@ -804,31 +826,48 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
         t.stop((1ull << 32) + count);
       }
       uint32_t h_cnt[4];
+      double t0 = now();
       HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       HIP_TRY(hipGetLastError());
+      t_kernel += now() - t0;
+      n_batches++;
       if (h_cnt[2]) {  // more deposits than the record buffers hold: redo these paths in smaller batches
         if (batch <= 1024) return fail(ctx, RT_ERR_OVERFLOW, "photon deposit buffer overflow");
         batch /= 4;
+        cap_batch = batch;  // do not grow past a size that overflowed
         continue;
       }
       for (int w = 0; w < 2; w++) {
         uint32_t m = h_cnt[w];
         if (!m || kept[w].size() >= n) continue;
+        double t1 = now();
         h_rec.resize(m);
         h_key.resize(m);
         HIP_TRY(hipMemcpy(h_rec.data(), d_rec[w], (size_t)m * 32, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(h_key.data(), d_key[w], (size_t)m * 8, hipMemcpyDeviceToHost));
-        // the sequential emitter stores deposits in (path, bounce) order and stops storing when the map is full
-        order.resize(m);
-        for (uint32_t i = 0; i < m; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-          uint64_t ka = (h_key[a] << 32) | (h_key[a] >> 32), kb = (h_key[b] << 32) | (h_key[b] >> 32);  // uint2 {path, bounce}
-          return ka < kb;
-        });
+        t_copy += now() - t1;
+        t1 = now();
+        // the sequential emitter stores deposits in (path, bounce) order and stops storing when the map is full:
+        // sort (path - first, bounce, record) packed in one word; only the part that still fits the map is needed
+        sorted.resize(m);
+        for (uint32_t i = 0; i < m; i++) {
+          uint64_t path = (uint32_t)h_key[i] - PP.first, bounce = h_key[i] >> 32;  // uint2 {path, bounce}
+          sorted[i] = (path << 32) | ((bounce & 0xffu) << 24) | i;
+        }
+        size_t want = std::min<size_t>(m, n - kept[w].size());
+        if (want < m) std::nth_element(sorted.begin(), sorted.begin() + want, sorted.end());
+        std::sort(sorted.begin(), sorted.begin() + want);
+        order.resize(want);
+        for (size_t i = 0; i < want; i++) order[i] = (uint32_t)(sorted[i] & 0xffffffu);
+        m = (uint32_t)want;
         for (uint32_t i = 0; i < m && kept[w].size() < n; i++) kept[w].push_back(h_rec[order[i]]);
+        t_sort += now() - t1;
       }
       emitted += count;
+      // deposits into a map that still accepts them decide how many paths the record buffers can take per batch
+      uint32_t densest = std::max(PP.accept[0] ? h_cnt[0] : 0u, PP.accept[1] ? h_cnt[1] : 0u);
+      while (batch < cap_batch && (uint64_t)densest * 8 < cap) { batch *= 2; densest *= 2; }
     }
     if (ctx->profile_on) {
       std::vector<uint32_t> none;
@@ -840,8 +879,18 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
   for (int w = 0; w < 2; w++)
     for (auto& p : kept[w]) p.power *= scale;
   int rc;
-  if ((rc = photon_upload_map(ps, ctx, 0, kept[0]))) return rc;
-  if ((rc = photon_upload_map(ps, ctx, 1, kept[1]))) return rc;
+  const double t_bal = now();
+  {  // PrepareForIrradianceEstimation of both maps at once (the reference balances them one after the other)
+    std::vector<rt_photon> bal[2];
+    std::thread other([&] { photon_balance(kept[1], bal[1]); });
+    photon_balance(kept[0], bal[0]);
+    other.join();
+    if ((rc = photon_upload_balanced(ps, ctx, 0, kept[0], bal[0]))) return rc;
+    if ((rc = photon_upload_balanced(ps, ctx, 1, kept[1], bal[1]))) return rc;
+  }
+  if (timing)
+    std::fprintf(stderr, "photon build: %.2f ms total; %d batches, %u paths; wait for kernels %.2f, deposit copies %.2f, ordering %.2f, balance + upload %.2f\n",
+                 now() - t_start, n_batches, emitted, t_kernel, t_copy, t_sort, now() - t_bal);
   ps.emitted = emitted;
   std::memcpy(ps.key, key, sizeof key);
   ps.built = true;
