@@ -568,7 +568,8 @@ RT_DEV void best_init(Best& B) {
 template <bool CNT, bool SPLIT>
 RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, bool& mesh_flag, uint32_t* stk, uint32_t stride,
                               Cnt<CNT>& cnt) {
-  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  V3 winv = v3(0, 0, 0);
+  if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   ParentRay pr;
@@ -693,7 +694,8 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 // SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
 template <bool CNT, bool SPLIT>
 RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
-  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  V3 winv = v3(0, 0, 0);
+  if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   ParentRay pr;

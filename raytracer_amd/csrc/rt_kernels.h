@@ -36,6 +36,8 @@ struct GroupQ {  // one record per (shade point, light) whose unshadowed contrib
   float4* g0;    // P.xyz, light index
   float4* g1;    // weight * unshadowed BRDF term rgb, path slot
   float4* g2;    // disc offsets rx, ry (lights.cpp:25-26), lit-sample counter, unused
+  float4* g3;    // soft groups: disc tangent (lights.cpp:32), light size     -- the same for every sample of the group,
+  float4* g4;    // soft groups: disc bitangent, unused                          computed once by k_shade
   uint32_t* counts;
   uint32_t segcap;
   uint32_t nseg;
@@ -815,6 +817,11 @@ RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, G
           GS.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
           GS.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
           GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), 0.0f);
+          V3 toSP = normalized(sp.P - v3(L->position[0], L->position[1], L->position[2]));  // lights.cpp:21-22, 31-32
+          V3 tangent, bitangent;
+          orthonormals(toSP, tangent, bitangent);
+          GS.g3[gi] = make_float4(tangent.x, tangent.y, tangent.z, L->size * P.light_size_scale);
+          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, 0.0f);
         }
       } else {
         uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
@@ -856,14 +863,12 @@ RT_DEV void hard_shadow_ray(const DScene& S, float4 g0, V3& Pp, V3& d, float& tm
   }
 }
 // Soft shadows, PointLight::Illuminate (lights.cpp:34-60): the ray of sample j of a group.
-RT_DEV void soft_shadow_ray(const DScene& S, const PassP& P, float4 g0, float4 g2, uint32_t j, V3& Pp, V3& d, float& dist) {
+RT_DEV void soft_shadow_ray(const DScene& S, float4 g0, float4 g2, float4 g3, float4 g4, uint32_t j, V3& Pp, V3& d, float& dist) {
   Pp = v3(g0.x, g0.y, g0.z);
   const DLight& L = S.lights[__float_as_uint(g0.w)];
   V3 position = v3(L.position[0], L.position[1], L.position[2]);
-  float size = L.size * P.light_size_scale;
-  V3 toSP = normalized(Pp - position);
-  V3 tangent, bitangent;
-  orthonormals(toSP, tangent, bitangent);
+  V3 tangent = v3(g3.x, g3.y, g3.z), bitangent = v3(g4.x, g4.y, g4.z);
+  float size = g3.w;
   const float twoPi = (float)(2 * RT_PI_D);
   float discX = S.halton[RT_H2 + (j & 127)] + g2.x;
   float discY = S.halton[RT_H3 + (j & 127)] + g2.y;
@@ -871,8 +876,10 @@ RT_DEV void soft_shadow_ray(const DScene& S, const PassP& P, float4 g0, float4 g
   discY -= (discY > 1.0f) ? 1.0f : 0.0f;
   float r = sqrtf(discX) * size;
   float angle = twoPi * discY;
-  float offsetU = r * cosf(angle);
-  float offsetV = r * sinf(angle);
+  float sn, cs;
+  sincosf(angle, &sn, &cs);
+  float offsetU = r * cs;
+  float offsetV = r * sn;
   V3 lsp = position + (tangent * offsetU) + (bitangent * offsetV);
   V3 toLight = lsp - Pp;
   dist = length(toLight);
@@ -929,7 +936,7 @@ RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_
       j = j0 + (uint32_t)(seg_e % nj);
       V3 Pp, d;
       float dist;
-      soft_shadow_ray(S, P, G.g0[g], G.g2[g], j, Pp, d, dist);
+      soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], G.g4[g], j, Pp, d, dist);
       rays++;
       bool occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
       if (occ) need_mesh = false;
@@ -990,7 +997,7 @@ RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
         if (wi != RT_NONE) {
           uint2 it = MQ.item2[wi];
           group = it.x;
-          if (SOFT) soft_shadow_ray(S, P, G.g0[group], G.g2[group], it.y, o, dir, tmax);
+          if (SOFT) soft_shadow_ray(S, G.g0[group], G.g2[group], G.g3[group], G.g4[group], it.y, o, dir, tmax);
           else hard_shadow_ray(S, G.g0[group], o, dir, tmax);
           winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
           W.mi = 0;

@@ -1038,8 +1038,12 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     void* pp;
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g0 = (float4*)pp;
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g1 = (float4*)pp;
-    g.g2 = nullptr;
-    if (with_g2) { if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp; }
+    g.g2 = g.g3 = g.g4 = nullptr;
+    if (with_g2) {
+      if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp;
+      if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g3 = (float4*)pp;
+      if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g4 = (float4*)pp;
+    }
     g.counts = nullptr;
     return (int)RT_OK;
   };
@@ -1241,7 +1245,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   const double fworst[7] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
                             meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0};
   auto per_path_bytes = [&](const double* f) {
-    return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 52.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
+    return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 84.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
   };
   // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
   // traversal kernels, and HBM is 288 GB
