@@ -31,9 +31,10 @@ class Config:
     """One BASELINE.json configuration.  The driver runs the default (c2, configs[1]: the largest that BASELINE quotes
     on ONE MI355X); the others are selectable with --config for the measurements recorded in BASELINE.md / DESIGN.md."""
 
-    def __init__(self, name, workload, width, height, spp_per_step, scene, tweak):
+    def __init__(self, name, workload, width, height, spp_per_step, scene, tweak, cpu_tile_stride=1):
         self.name, self.workload, self.width, self.height = name, workload, width, height
         self.spp_per_step, self.scene_fn, self.tweak = spp_per_step, scene, tweak
+        self.cpu_tile_stride = cpu_tile_stride   # the CPU baseline renders every n-th 32x32 tile (bounded sample)
 
     def scene(self):
         return self.scene_fn()
@@ -85,11 +86,11 @@ CONFIGS = {
                  lambda p: None),
     "c3": Config("c3", "C3: scenes/c3_cornell_textured.xml (Cornell box, checker floor, brick wall, cloud environment), Monte-Carlo "
                  "indirect diffuse 2 bounces + 3 specular bounces, soft shadows 16..128 rays; 8 of the 1024 spp per step", 3840, 2160, 8,
-                 _load("scenes/c3_cornell_textured.xml"), _c3),
+                 _load("scenes/c3_cornell_textured.xml"), _c3, cpu_tile_stride=16),
     "c4": Config("c4", "C4: Cornell box (tests/golden/scenes/cornell_box.xml), 2 x 100k photons rebuilt every step, k=128 r=3 gather, "
-                 "soft shadows, 3 bounces", 1920, 1080, 8, _load("tests/golden/scenes/cornell_box.xml"), _c4),
+                 "soft shadows, 3 bounces", 1920, 1080, 8, _load("tests/golden/scenes/cornell_box.xml"), _c4, cpu_tile_stride=8),
     "c5": Config("c5", "C5: synthetic stress scene, 12.6 M triangles in one BVH (2048 icospheres + displaced ground), 2 sphere "
-                 "lights, 3 bounces; 4 of the 4096 spp per step", 3840, 2160, 4, _stress, lambda p: None),
+                 "lights, 3 bounces; 4 of the 4096 spp per step", 3840, 2160, 4, _stress, lambda p: None, cpu_tile_stride=509),
 }
 
 
@@ -102,19 +103,25 @@ def cpu_baseline(cfg, scene, target_seconds=12.0):
     orc = oracle_ffi.OracleScene(scene)
     WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
     p = cfg.params(0)
+    p.tile_begin, p.tile_stride, p.tile_count = 0, cfg.cpu_tile_stride, 0
+    if p.photons:
+        orc.photons_build(p)   # (outside the timed region: the GPU side's ray count excludes photon rays as well)
     p.sample_count = 1
     t0 = time.perf_counter()
     _, cnt = orc.render(p, cores, want_counters=True)
     t1 = time.perf_counter() - t0
-    spp = int(max(1, min(8 * SPP_PER_STEP, target_seconds / max(t1, 1e-3))))
-    p.sample_count = spp
-    t0 = time.perf_counter()
-    _, cnt = orc.render(p, cores, want_counters=True)
-    dt = time.perf_counter() - t0
+    spp, dt = 1, t1
+    if t1 < 0.5 * target_seconds:
+        spp = int(max(1, min(8 * SPP_PER_STEP, target_seconds / max(t1, 1e-3))))
+        p.sample_count = spp
+        t0 = time.perf_counter()
+        _, cnt = orc.render(p, cores, want_counters=True)
+        dt = time.perf_counter() - t0
     rays = cnt["rays_primary"] + cnt["rays_secondary"] + cnt["rays_shadow"]
+    tiles = "all 32x32 tiles" if cfg.cpu_tile_stride == 1 else f"every {cfg.cpu_tile_stride}th 32x32 tile"
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{WIDTH}x{HEIGHT} x {spp} spp of the same scene/params, {rays} rays in {dt:.2f} s, oracle/liboracle.so "
-                      f"(reference structure: no TLAS, BVH visits both children), {cores} threads"}
+            "sample": f"{WIDTH}x{HEIGHT}, {tiles}, {spp} spp of the same scene/params, {rays} rays in {dt:.2f} s, oracle/liboracle.so "
+                      f"(reference structure: no TLAS, BVH visits both children, kd-tree + heap photon gather), {cores} threads"}
 
 
 def main():
@@ -196,18 +203,30 @@ def main():
         n_expected = SPP_PER_STEP * world
         assert abs(float(img.radiance[..., 3].mean()) - n_expected) < 1e-3, "accumulator does not hold the expected samples"
 
-        # SURVEY §8d algorithmic bytes of the two closest-hit kernels: 48 B per ray or work item (32 B ray in, 16 B hit
-        # out) + 32 B per BVH box tested (two per 64-byte node fetch) + 48 B per triangle slot + 96 B per instance
-        # transform pair.  All BVH node / triangle work of the closest-hit stage happens in k_trace_mesh; the instance
-        # table (spheres, planes, mesh world boxes) is walked by k_trace_closest.
+        # SURVEY §8d algorithmic bytes / flops of the traversal and gather kernels: 48 B per ray or work item (32 B ray in,
+        # 16 B hit / occlusion out) + 32 B per BVH box tested (two per 64-byte node fetch) + 48 B per triangle slot + 96 B
+        # per instance transform pair + 32 B per photon visited; 36 flops per instance, 30 per sphere, 12 per plane, 24 per
+        # box, 51 per triangle, 20 per photon.  BVH work happens in the mesh kernels (second phase); the instance table
+        # (spheres, planes, mesh world boxes) is walked by the first-phase kernels.
         tc_rays = cnt["rays_primary"] + cnt["rays_secondary"]
         first_inst = cnt["closest_inst_tests"] - cnt["mesh_inst_tests"]
+        sh_inst = cnt["inst_tests"] - cnt["closest_inst_tests"]          # shadow-ray instance tests, both phases
+        sh_nodes = cnt["node_visits"] - cnt["closest_node_visits"]
+        sh_tris = cnt["tri_tests"] - cnt["closest_tri_tests"]
         kern = {
-            "k_trace_closest": (prof["trace_closest"], 48.0 * tc_rays + 96.0 * first_inst, 36.0 * first_inst),
+            "k_trace_closest": (prof["trace_closest"], 48.0 * tc_rays + 96.0 * first_inst,
+                                36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
+                                / max(tc_rays + cnt["rays_shadow"], 1)),
             "k_trace_mesh": (prof["trace_mesh"],
                              48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"]
                              + 96.0 * cnt["mesh_inst_tests"],
                              36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"]),
+            # shadow rays, first phase (k_shadow_hard / k_shadow_soft): every instance test is charged here
+            "k_shadow": (prof["shadow"], 48.0 * cnt["rays_shadow"] + 96.0 * sh_inst,
+                         36.0 * sh_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * cnt["rays_shadow"]
+                         / max(tc_rays + cnt["rays_shadow"], 1)),
+            "k_shadow_mesh": (prof["shadow_mesh"], 32.0 * sh_nodes + 48.0 * sh_tris, 24.0 * sh_nodes + 51.0 * sh_tris),
+            "k_photon_gather": (prof["photon_gather"], 32.0 * cnt["photon_visits"] + 48.0 * cnt["gathers"], 20.0 * cnt["photon_visits"]),
         }
         dom = max(kern, key=lambda k: kern[k][0]["ms"])   # the kernel with the most time in the timed region
         tc, tc_bytes, tc_flops = kern[dom]

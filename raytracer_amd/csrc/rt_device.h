@@ -313,6 +313,23 @@ RT_DEV bool box_test_fast(V3 p, V3 inv, float b0, float b1, float b2, float b3, 
   tmin_out = tmin;
   return tmax >= tmin && tmax >= 0.0f;
 }
+// Both children of a 64-byte node (layout per axis: left min, right min, left max, right max): the same arithmetic as
+// box_test_fast per child, written pairwise so that it compiles to packed FP32 operations without register shuffles.
+RT_DEV void box_test_fast2(V3 p, V3 inv, float4 nx, float4 ny, float4 nz, bool& hl, bool& hr, float& tl, float& tr) {
+  float t1l = (nx.x - p.x) * inv.x, t1r = (nx.y - p.x) * inv.x;
+  float t2l = (nx.z - p.x) * inv.x, t2r = (nx.w - p.x) * inv.x;
+  float t3l = (ny.x - p.y) * inv.y, t3r = (ny.y - p.y) * inv.y;
+  float t4l = (ny.z - p.y) * inv.y, t4r = (ny.w - p.y) * inv.y;
+  float t5l = (nz.x - p.z) * inv.z, t5r = (nz.y - p.z) * inv.z;
+  float t6l = (nz.z - p.z) * inv.z, t6r = (nz.w - p.z) * inv.z;
+  float tminl = fmaxf(fmaxf(fminf(t1l, t2l), fminf(t3l, t4l)), fminf(t5l, t6l));
+  float tminr = fmaxf(fmaxf(fminf(t1r, t2r), fminf(t3r, t4r)), fminf(t5r, t6r));
+  float tmaxl = fminf(fminf(fmaxf(t1l, t2l), fmaxf(t3l, t4l)), fmaxf(t5l, t6l));
+  float tmaxr = fminf(fminf(fmaxf(t1r, t2r), fmaxf(t3r, t4r)), fmaxf(t5r, t6r));
+  tl = tminl; tr = tminr;
+  hl = tmaxl >= tminl && tmaxl >= 0.0f;
+  hr = tmaxr >= tminr && tmaxr >= 0.0f;
+}
 template <bool FAST>
 RT_DEV bool box_test_sel(V3 p, V3 inv, float b0, float b1, float b2, float b3, float b4, float b5, float& tmin_out) {
   if (FAST) return box_test_fast(p, inv, b0, b1, b2, b3, b4, b5, tmin_out);
@@ -397,8 +414,8 @@ RT_DEV bool mesh_closest_t(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, 
     float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
     float tl, tr;
     cnt.node(2);
-    bool hl = box_test_sel<FAST>(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-    bool hr = box_test_sel<FAST>(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+    bool hl = box_test_sel<FAST>(p, inv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl);
+    bool hr = box_test_sel<FAST>(p, inv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr);
     float bound = prune_bound(best_t < t_bound ? best_t : t_bound);
     hl = hl && tl <= bound;
     hr = hr && tr <= bound;
@@ -458,8 +475,8 @@ RT_DEV bool mesh_any_t(const DScene& S, const DMesh& M, V3 p, V3 d, V3 inv, floa
     float4 n0 = nodes[4 * cur], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
     float tl, tr;
     cnt.node(2);
-    bool hl = box_test_sel<FAST>(p, inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl) && tl <= bound;
-    bool hr = box_test_sel<FAST>(p, inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr) && tr <= bound;
+    bool hl = box_test_sel<FAST>(p, inv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl) && tl <= bound;
+    bool hr = box_test_sel<FAST>(p, inv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr) && tr <= bound;
     uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
     if (hl && hr) {
       stk[(sp++) * stride] = cr;
@@ -808,11 +825,11 @@ RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 
                            Cnt<CNT>& cnt) {
   float tl, tr;
   cnt.node(2);
-  bool hl = box_test_fast(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-  bool hr = box_test_fast(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+  bool hl, hr;
+  box_test_fast2(W.p, W.inv, n0, n1, n2, hl, hr, tl, tr);
   if (!W.fast) {  // a zero direction component: the literal hitAABB form (NaN behaviour of FAST_MIN / FAST_MAX)
-    hl = box_test(W.p, W.inv, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tl);
-    hr = box_test(W.p, W.inv, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr);
+    hl = box_test(W.p, W.inv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl);
+    hr = box_test(W.p, W.inv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr);
   }
   float bound = prune_bound(bound_t);
   hl = hl && tl <= bound;

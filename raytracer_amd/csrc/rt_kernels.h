@@ -1012,10 +1012,11 @@ RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
 #pragma unroll
       for (int k = 0; k < RT_NODE_BATCH; k++) {
         if (k > 0 && walking && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
-        const bool an = walking && ref_is_node(W.cur);
-        float4 n0, n1, n2, n3;
-        fetch_node(S, W, an, n0, n1, n2, n3);
-        if (an) mesh_walk_node<CNT, false>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+        if (walking && ref_is_node(W.cur)) {
+          float4 n0, n1, n2, n3;
+          fetch_node(S, W, true, n0, n1, n2, n3);
+          mesh_walk_node<CNT, false>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+        }
       }
     } else if (walking && W.pend != 0) {
       bool occluded = mesh_walk_leaf_any<CNT>(S, W, W.pend, tmax, cnt);

@@ -257,9 +257,10 @@ struct MeshConv {
     uint32_t lref, rref;
     if (!convert(n.a, depth + 1, lref)) return false;
     if (!convert(n.b, depth + 1, rref)) return false;
-    nodes[at + 0] = make_float4(l.bmin[0], l.bmin[1], l.bmin[2], l.bmax[0]);
-    nodes[at + 1] = make_float4(l.bmax[1], l.bmax[2], r.bmin[0], r.bmin[1]);
-    nodes[at + 2] = make_float4(r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]);
+    // per axis: (left min, right min, left max, right max) — the two children's slab tests run as packed FP32 pairs
+    nodes[at + 0] = make_float4(l.bmin[0], r.bmin[0], l.bmax[0], r.bmax[0]);
+    nodes[at + 1] = make_float4(l.bmin[1], r.bmin[1], l.bmax[1], r.bmax[1]);
+    nodes[at + 2] = make_float4(l.bmin[2], r.bmin[2], l.bmax[2], r.bmax[2]);
     nodes[at + 3] = make_float4(host_u2f(lref), host_u2f(rref), 0.0f, 0.0f);
     ref = me;
     return true;
@@ -1165,22 +1166,36 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       }
     }
     if (any_soft) {
-      Timer t(ctx, RT_K_SHADOW);
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
       MeshQ MS1 = meshq(ctx->MS, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
-      LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
-               (uint32_t)P.shadow_min, MS1);
-      if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
+      {
+        Timer t(ctx, RT_K_SHADOW);
+        LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+                  (uint32_t)P.shadow_min, MS1);
+        t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
+      }
+      if (meshes) {
+        Timer t(ctx, RT_K_SHADOW_MESH);
+        LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
+        t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS1));
+      }
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
         uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
-        LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
-                 (uint32_t)P.shadow_min, nr, MS2);
-        if (meshes) LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
+        {
+          Timer t(ctx, RT_K_SHADOW);
+          LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
+                    (uint32_t)P.shadow_min, nr, MS2);
+          t.stop((uint64_t)(lvl * CNT_KINDS + CNT_N2));
+        }
+        if (meshes) {
+          Timer t(ctx, RT_K_SHADOW_MESH);
+          LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
+          t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS2));
+        }
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
-      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
     }
     if (photons) {
       Timer t(ctx, RT_K_PHOTON_GATHER);
