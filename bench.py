@@ -153,27 +153,42 @@ def main():
     r = Renderer(local_rank)
     r.LoadScene(scene)
     p = cfg.params(rank)
-    accum = torch.zeros(WIDTH * HEIGHT * 8, dtype=torch.float32, device=f"cuda:{local_rank}")
+    # two frame accumulators: the RCCL exchange of one frame overlaps the rendering of the next (N > 1)
+    accums = [torch.zeros(WIDTH * HEIGHT * 8, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if world > 1 else 1)]
+    pending = [None] * len(accums)
+    frame = [0]
 
     def step():
+        k = frame[0] % len(accums)
+        frame[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()
+        accum = accums[k]
         accum.zero_()
         torch.cuda.synchronize()
         if p.photons:
             r.BuildPhotonMaps(p)  # GeneratePhotons is part of every BeginRender (RayTracer.cpp:24-40)
-        # blocking render of this rank's sample range into `accum`, then the sample-split exchange:
-        # one RCCL sum-reduce of the accumulators to rank 0 over xGMI
-        distributed.render_partition(r, p, accum)
+        # blocking render of this rank's sample range into `accum`, then the sample-split exchange: one RCCL
+        # sum-reduce of (sum rgb, n) to rank 0 over xGMI, left in flight while the next frame renders
+        pending[k] = distributed.render_partition(r, p, accum, async_op=world > 1)
+
+    def drain():
+        for q in pending:
+            if q is not None:
+                q.wait()
+        torch.cuda.synchronize()
 
     # one counted, untimed step: algorithmic work per step
     r.counters(enable=True, reset=True)
     step()
-    torch.cuda.synchronize()
+    drain()
     cnt = r.counters()
     r.counters(enable=False)
     rays_per_step = cnt["rays_primary"] + cnt["rays_secondary"] + cnt["rays_shadow"]
 
     for _ in range(args.warmup):
         step()
+    drain()
     r.profile(enable=True, reset=True)
     if world > 1:
         dist.barrier()
@@ -181,7 +196,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    drain()   # every frame's exchange has completed on rank 0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -199,6 +214,7 @@ def main():
     if rank == 0:
         # final image of the last step (outside the timed region): sanity that the accumulators hold a frame
         pr = cfg.params(0)
+        accum = accums[(frame[0] - 1) % len(accums)]
         img = r.resolve(pr, accum.data_ptr())
         n_expected = SPP_PER_STEP * world
         assert abs(float(img.radiance[..., 3].mean()) - n_expected) < 1e-3, "accumulator does not hold the expected samples"
@@ -249,7 +265,7 @@ def main():
                        "triangles": scene.n_triangles(),
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
-                       "partition": "sample-range split, RCCL sum-reduce of the accumulator" if world > 1 else "single GPU",
+                       "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

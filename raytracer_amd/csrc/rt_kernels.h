@@ -602,7 +602,10 @@ RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs,
 // Every lane of a wave runs every queue-append site of an iteration (predicated), so the per-wave chunk state of
 // wave_push stays uniform; see WavePush.
 template <bool CNT>
-RT_KERNEL(k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4   // measured on the C2 bench: 2 -> 7.37 ms, 3 -> 6.52 ms, 4 -> 6.26 ms per step
+#endif
+RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
   RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);

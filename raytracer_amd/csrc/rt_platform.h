@@ -16,6 +16,8 @@
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_MEM __device__ __forceinline__
 #define RT_KERNEL(name, ...) __global__ void __launch_bounds__(256) name(__VA_ARGS__)
+// a kernel held to `w` waves per SIMD (register budget 512 / w)
+#define RT_KERNEL_W(w, name, ...) __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(w, w))) name(__VA_ARGS__)
 #define RT_TID ((uint32_t)(blockIdx.x * blockDim.x + threadIdx.x))
 #define RT_NTHREADS ((uint32_t)(gridDim.x * blockDim.x))
 #define RT_LANE_IN_BLOCK ((uint32_t)threadIdx.x)
@@ -30,6 +32,7 @@
 #define RT_HD static inline
 #define RT_MEM inline
 #define RT_KERNEL(name, ...) static void name(__VA_ARGS__)
+#define RT_KERNEL_W(w, name, ...) static void name(__VA_ARGS__)
 #define RT_TID 0u
 #define RT_NTHREADS 1u
 #define RT_LANE_IN_BLOCK 0u

@@ -33,9 +33,43 @@ def tile_split_params(params, rank, world):
     return p
 
 
-def render_partition(renderer, params, accum, group=None, dst=0):
-    """Renders this rank's share into `accum` and sums all shares on rank `dst` (no-op reduce for one rank)."""
+class PendingReduce:
+    """An accumulator exchange in flight (RCCL runs it on its own stream); wait() completes it on `dst`."""
+
+    def __init__(self, accum, packed, work, is_dst):
+        self.accum, self.packed, self.work, self.is_dst = accum, packed, work, is_dst
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.packed is not None and self.is_dst:
+            self.accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4] = self.packed.view(-1, 4)
+        self.packed = None
+        return self.accum
+
+
+def reduce_accumulators(accum, group=None, dst=0, sums_only=True, async_op=False):
+    """Sums the ranks' accumulators on rank `dst`.  sums_only: exchange (sum rgb, n) only — half the bytes; the sums of
+    squares and the done flag matter to adaptive sampling alone, which partitioned rendering does not use (fixed spp)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return PendingReduce(accum, None, None, True)
+    is_dst = dist.get_rank(group) == dst
+    if sums_only:
+        packed = accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4].contiguous()
+        work = dist.reduce(packed, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending = PendingReduce(accum, packed, work, is_dst)
+    else:
+        work = dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending = PendingReduce(accum, None, work, is_dst)
+    if not async_op:
+        pending.wait()
+    return pending
+
+
+def render_partition(renderer, params, accum, group=None, dst=0, sums_only=True, async_op=False):
+    """Renders this rank's share into `accum` (blocking), then sums all shares on rank `dst` (no exchange for one rank).
+    async_op: returns with the exchange still in flight so that the next frame's rendering overlaps it; the caller
+    keeps `accum` untouched until PendingReduce.wait()."""
     renderer.render_accumulate(params, accum.data_ptr())
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return accum
+    return reduce_accumulators(accum, group=group, dst=dst, sums_only=sums_only, async_op=async_op)

@@ -37,9 +37,23 @@ def _worker(rank, world, port, mode, out_path):
     r = emu_ffi.EmuRenderer()
     r.LoadScene(scene)
     base = params(W, H, spp=SPP * world, jitter=1, bounces=2)
-    p = distributed.sample_split_params(base, rank, SPP) if mode == "sample" else distributed.tile_split_params(base, rank, world)
-    acc = distributed.alloc_accumulator(W, H, "cpu")
-    distributed.render_partition(r, p, acc)
+    p = distributed.sample_split_params(base, rank, SPP) if mode.startswith("sample") else distributed.tile_split_params(base, rank, world)
+    if mode == "sample_pipelined":
+        # bench.py's N > 1 loop: two accumulators, each frame's exchange left in flight while the next frame renders
+        accs = [distributed.alloc_accumulator(W, H, "cpu") for _ in range(2)]
+        pend = [None, None]
+        for frame in range(3):
+            k = frame % 2
+            if pend[k] is not None:
+                pend[k].wait()
+            accs[k].zero_()
+            pend[k] = distributed.render_partition(r, p, accs[k], async_op=True)
+        for q in pend:
+            q.wait()
+        acc = accs[0]   # frame 2
+    else:
+        acc = distributed.alloc_accumulator(W, H, "cpu")
+        distributed.render_partition(r, p, acc, sums_only=(mode != "sample_full"))
     dist.barrier()
     if rank == 0:
         img = r.resolve(base, acc.data_ptr())
@@ -49,7 +63,7 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sample", "tile"])
+@pytest.mark.parametrize("mode", ["sample", "sample_full", "sample_pipelined", "tile"])
 def test_two_rank_partition_equals_single_render(tmp_path, mode):
     out = str(tmp_path / f"{mode}.npz")
     mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
