@@ -205,6 +205,13 @@ typedef struct rt_framebuffer {
   int32_t* hit_face;      /* W*H: face id for mesh hits, else -1 */
   int32_t on_device;
   int32_t reserved;
+  /* Geometry buffers of the first camera sample's primary hit: what the viewer reads from RenderImage::zbuffer
+   * (renderer.h:39,74; the reference's RunThread stores 0 there, RayTracer.cpp:215) and the guide images of the
+   * Denoise(color, albedo, normal) overload the reference declares (denoiser.h:16-17). */
+  float* depth;           /* W*H: distance from the ray origin to the hit (HitInfo::z after SetHit), BIGFLOAT on a miss */
+  float* normal;          /* W*H*3: unit shading normal in world space; 0 for a miss or a light */
+  float* albedo;          /* W*H*3: the material's diffuse colour at the hit (texture included); the background colour
+                             on a miss, 1 for a light or a non-Blinn material */
 } rt_framebuffer;
 
 /* Algorithmic work counters. */

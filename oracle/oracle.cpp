@@ -187,6 +187,8 @@ struct Hit {  // scene.h:74-90
   bool front;
   int light;  // -1, or index of the renderable light hit (the reference keeps a bool)
   int face;
+  float aov_depth;  // filled for the primary hit of the AOV sample only (rt_framebuffer depth / normal / albedo)
+  V aov_normal, aov_albedo;
   Hit() { init(); }
   void init() {
     z = BIGFLOAT; node = -1; uvw = V(0.5f, 0.5f, 0.5f); front = true; light = -1; face = -1;
@@ -1274,7 +1276,19 @@ Color send_ray(const orc_scene& S, const rt_render_params& P, int i, const Ray& 
   Hit hit;
   if (cnt) { cnt->rays_primary++; cnt->paths++; }
   bool ok = traverse(S, ray, 0, hit, RT_HIT_FRONT, cnt);
-  if (primary_out) *primary_out = hit;
+  if (primary_out) {
+    *primary_out = hit;
+    primary_out->aov_depth = ok ? hit.z * length(ray.dir) : BIGFLOAT;
+    primary_out->aov_normal = V();
+    primary_out->aov_albedo = V(1.0f, 1.0f, 1.0f);
+    if (ok && hit.light < 0) {
+      primary_out->aov_normal = normalized(hit.N);
+      const rt_material& M = node_material(S, hit.node);
+      if (M.kind == RT_MTL_BLINN) primary_out->aov_albedo = eval_tex_color(S, M.diffuse, hit.uvw, nullptr);
+    } else if (!ok) {
+      primary_out->aov_albedo = eval_tex_color(S, S.d.background, V((float)x / (float)W, (float)y / (float)H, 0.0f), nullptr);
+    }
+  }
   if (ok) {
     if (hit.light < 0) {
       ShadeCtx info;
@@ -1368,6 +1382,9 @@ void render_pixel(RenderJob& job, int x, int y, Counters* cnt) {
   if (fb->sample_count) fb->sample_count[index] = total;
   if (fb->hit_node) fb->hit_node[index] = first.light >= 0 ? -2 - first.light : first.node;
   if (fb->hit_face) fb->hit_face[index] = first.light >= 0 ? -1 : first.face;
+  if (fb->depth) fb->depth[index] = first.aov_depth;
+  if (fb->normal) { fb->normal[3 * (size_t)index] = first.aov_normal.x; fb->normal[3 * (size_t)index + 1] = first.aov_normal.y; fb->normal[3 * (size_t)index + 2] = first.aov_normal.z; }
+  if (fb->albedo) { fb->albedo[3 * (size_t)index] = first.aov_albedo.x; fb->albedo[3 * (size_t)index + 1] = first.aov_albedo.y; fb->albedo[3 * (size_t)index + 2] = first.aov_albedo.z; }
 }
 
 void run_thread(RenderJob* job, Counters* cnt) {  // RayTracer.cpp:93-116: 32x32 tiles off one atomic

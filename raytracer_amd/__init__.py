@@ -104,6 +104,9 @@ class RenderImage:
         self.sample_count = np.zeros((h, w), np.int32)
         self.hit_node = np.full((h, w), -1, np.int32)
         self.hit_face = np.full((h, w), -1, np.int32)
+        self.zbuffer = np.zeros((h, w), np.float32)       # RenderImage::zbuffer (renderer.h:39)
+        self.normal = np.zeros((h, w, 3), np.float32)
+        self.albedo = np.zeros((h, w, 3), np.float32)
 
     def framebuffer(self):
         fb = rt_framebuffer()
@@ -112,6 +115,9 @@ class RenderImage:
         fb.sample_count = self.sample_count.ctypes.data
         fb.hit_node = self.hit_node.ctypes.data
         fb.hit_face = self.hit_face.ctypes.data
+        fb.depth = self.zbuffer.ctypes.data
+        fb.normal = self.normal.ctypes.data
+        fb.albedo = self.albedo.ctypes.data
         fb.on_device = 0
         return fb
 

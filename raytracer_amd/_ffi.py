@@ -108,7 +108,8 @@ class rt_render_params(C.Structure):
 
 class rt_framebuffer(C.Structure):
     _fields_ = [("rgb8", C.c_void_p), ("radiance", C.c_void_p), ("sample_count", C.c_void_p),
-                ("hit_node", C.c_void_p), ("hit_face", C.c_void_p), ("on_device", C.c_int32), ("reserved", C.c_int32)]
+                ("hit_node", C.c_void_p), ("hit_face", C.c_void_p), ("on_device", C.c_int32), ("reserved", C.c_int32),
+                ("depth", C.c_void_p), ("normal", C.c_void_p), ("albedo", C.c_void_p)]
 
 
 class rt_counters(C.Structure):

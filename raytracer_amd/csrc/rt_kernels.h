@@ -88,6 +88,9 @@ struct FrameBufs {
   float* accum;            // W*H*8: sum rgb, n, sum of squares rgb, done flag
   int32_t* hit_node;       // W*H AOVs (may be null)
   int32_t* hit_face;
+  float* aov_depth;        // W*H, W*H*3, W*H*3: geometry buffers of the AOV sample's primary hit (may be null)
+  float* aov_normal;
+  float* aov_albedo;
   uint32_t* overflow;
   DCounters* counters;
 };
@@ -621,6 +624,9 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
     bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
 
     bool surface = false;
+    const bool aov = bounce == 0 && F.aov_depth && (int)m.z == P.aov_sample && valid;
+    V3 aov_n = v3(0, 0, 0), aov_a = v3(1, 1, 1);
+    float aov_z = RT_BIG;
     ShadePt sp;
     sp.P = sp.N = sp.V = sp.uvw = v3(0, 0, 0);
     sp.front = true; sp.pixel = pixel; sp.nid = nid; sp.sample = (int)m.z;
@@ -665,12 +671,15 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         if (bounce == 0) {          // RayTracer.cpp:253-258
           float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
           float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
-          add_radiance(F, slot, w * eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt));
+          V3 bg = eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt);
+          aov_a = bg;
+          add_radiance(F, slot, w * bg);
         } else {                    // lights.cpp:204-208, dist = BIGFLOAT
           V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
           add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
         }
       } else if (light >= 0) {
+        aov_z = z * length(rdir);
         if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
           const DLight& L = S.lights[light];
           V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
@@ -692,6 +701,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           w = absorb(w, pabs, dist);
         }
         n_shades++;
+        aov_z = zs; aov_n = sp.N;
         const DMaterial& M = S.materials[S.inst[inst].mtl];
         if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
           add_radiance(F, slot, w);
@@ -701,6 +711,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
           V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
           kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
+          aov_a = kd;
           V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
           alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
           V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
@@ -769,6 +780,11 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
       }
     }
 
+    if (aov) {
+      F.aov_depth[pixel] = aov_z;
+      F.aov_normal[3 * (size_t)pixel] = aov_n.x; F.aov_normal[3 * (size_t)pixel + 1] = aov_n.y; F.aov_normal[3 * (size_t)pixel + 2] = aov_n.z;
+      F.aov_albedo[3 * (size_t)pixel] = aov_a.x; F.aov_albedo[3 * (size_t)pixel + 1] = aov_a.y; F.aov_albedo[3 * (size_t)pixel + 2] = aov_a.z;
+    }
     // ---- queue appends (all lanes of the wave pass through here)
     uint32_t ci = seg_push(p_refr, QN.counts, oseg, QN.segcap, F.overflow);
     if (ci != RT_NONE) write_child(QN, ci, c_refr, mabs, slot, pixel, m.z);

@@ -105,6 +105,7 @@ struct rt_context {
   uint32_t* d_pixels2 = nullptr;
   int32_t* d_hit_node = nullptr;
   int32_t* d_hit_face = nullptr;
+  float *d_aov_depth = nullptr, *d_aov_normal = nullptr, *d_aov_albedo = nullptr;
   DCounters* d_counters = nullptr;
   uint32_t path_budget = 0;
   // queue sizing: entries per camera sample in the fullest segment, by queue kind (measured by a pilot pass)
@@ -1080,6 +1081,9 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 8, &p))) return rc; ctx->d_pixels2 = (uint32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_hit_node = (int32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_hit_face = (int32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_aov_depth = (float*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 12, &p))) return rc; ctx->d_aov_normal = (float*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 12, &p))) return rc; ctx->d_aov_albedo = (float*)p;
   std::memcpy(ctx->frame_key, key, sizeof key);
   std::memset(ctx->pixel_key, 0, sizeof ctx->pixel_key);
   ctx->path_budget = fp.budget;
@@ -1299,6 +1303,9 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   if (n_pix_total == 0) return RT_OK;
   HIP_TRY(hipMemsetAsync(ctx->d_hit_node, 0xff, (size_t)W * H * 4, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->d_hit_face, 0xff, (size_t)W * H * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_aov_depth, 0, (size_t)W * H * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_aov_normal, 0, (size_t)W * H * 12, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->d_aov_albedo, 0, (size_t)W * H * 12, ctx->stream));
 
   PassP P;
   std::memset(&P, 0, sizeof P);
@@ -1332,6 +1339,9 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   F.accum = d_accum;
   F.hit_node = ctx->d_hit_node;
   F.hit_face = ctx->d_hit_face;
+  F.aov_depth = ctx->d_aov_depth;
+  F.aov_normal = ctx->d_aov_normal;
+  F.aov_albedo = ctx->d_aov_albedo;
   F.overflow = ctx->d_counts + CNT_OVERFLOW;
   F.counters = ctx->d_counters;
 
@@ -1426,9 +1436,15 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     std::memcpy(ctx->pixel_key, pkey, sizeof pkey);
     HIP_TRY(hipMemsetAsync(ctx->d_hit_node, 0xff, (size_t)W * H * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_hit_face, 0xff, (size_t)W * H * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_aov_depth, 0, (size_t)W * H * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_aov_normal, 0, (size_t)W * H * 12, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_aov_albedo, 0, (size_t)W * H * 12, ctx->stream));
     F.path_rad = ctx->d_path_rad;
     F.hit_node = ctx->d_hit_node;
     F.hit_face = ctx->d_hit_face;
+    F.aov_depth = ctx->d_aov_depth;
+    F.aov_normal = ctx->d_aov_normal;
+    F.aov_albedo = ctx->d_aov_albedo;
     F.overflow = ctx->d_counts + CNT_OVERFLOW;
   }
 
@@ -1493,6 +1509,9 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
     LAUNCH(k_resolve, npx, W, H, c.srgb, d_accum, (uint8_t*)fb->rgb8, (float*)fb->radiance, (int32_t*)fb->sample_count);
     if (fb->hit_node) HIP_TRY(hipMemcpyAsync(fb->hit_node, ctx->d_hit_node, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
     if (fb->hit_face) HIP_TRY(hipMemcpyAsync(fb->hit_face, ctx->d_hit_face, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fb->depth) HIP_TRY(hipMemcpyAsync(fb->depth, ctx->d_aov_depth, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fb->normal) HIP_TRY(hipMemcpyAsync(fb->normal, ctx->d_aov_normal, npx * 12, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fb->albedo) HIP_TRY(hipMemcpyAsync(fb->albedo, ctx->d_aov_albedo, npx * 12, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
   }
@@ -1509,6 +1528,9 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
   if (e == hipSuccess && fb->sample_count) e = hipMemcpyAsync(fb->sample_count, d_sc, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && fb->hit_node && ctx->d_hit_node) e = hipMemcpyAsync(fb->hit_node, ctx->d_hit_node, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && fb->hit_face && ctx->d_hit_face) e = hipMemcpyAsync(fb->hit_face, ctx->d_hit_face, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->depth && ctx->d_aov_depth) e = hipMemcpyAsync(fb->depth, ctx->d_aov_depth, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->normal && ctx->d_aov_normal) e = hipMemcpyAsync(fb->normal, ctx->d_aov_normal, npx * 12, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && fb->albedo && ctx->d_aov_albedo) e = hipMemcpyAsync(fb->albedo, ctx->d_aov_albedo, npx * 12, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   free_pool(tmp);
   if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));

@@ -56,3 +56,21 @@ def assert_hits_equal(gpu, cpu, what=""):
         assert (d / s).max(initial=0) <= 1e-5, f"{what}: {k} differs by {(d / s).max()}"
     d = np.abs(gpu["uvw"][surf] - cpu["uvw"][surf])
     assert d.max(initial=0) <= 1e-5, f"{what}: uvw differs by {d.max()}"
+
+
+def check_geometry_buffers(r, scene, w, h):
+    """depth / normal / albedo of the first camera sample's primary hit against the oracle."""
+    import oracle_ffi
+    r.LoadScene(scene)
+    p = params(w, h, spp=2, jitter=1, bounces=1)
+    g = r.Render(p)
+    c = oracle_ffi.OracleScene(scene).render(p)
+    assert np.array_equal(g.hit_node, c.hit_node)
+    hit = np.isfinite(c.zbuffer) & (c.zbuffer < 1e30)
+    assert hit.mean() > 0.3 and (~hit).sum() == (g.zbuffer >= 1e30).sum()
+    assert np.allclose(g.zbuffer[hit], c.zbuffer[hit], rtol=1e-6)
+    assert np.array_equal(g.zbuffer[~hit], c.zbuffer[~hit])
+    assert np.abs(g.normal - c.normal).max() <= 1e-5
+    assert np.abs(g.albedo - c.albedo).max() <= 1e-6
+    surf = c.hit_node >= 0
+    assert np.allclose(np.linalg.norm(c.normal[surf], axis=1), 1.0, atol=1e-5)

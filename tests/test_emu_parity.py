@@ -7,8 +7,11 @@ import pytest
 
 import emu_ffi
 import oracle_ffi
+import os
+
+import common as common_checks
 from common import assert_hits_equal, params, psnr8, random_rays, rel_colour_diff
-from conftest import scene_path
+from conftest import ROOT, scene_path
 from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, Scene
 
 TEXTURED = """<xml><scene>
@@ -186,3 +189,10 @@ def test_undersized_queues_split_the_pass_and_still_match(monkeypatch):
     assert (g.radiance[..., 3] == 4).all()
     for k in ("rays_primary", "rays_secondary", "paths", "shades"):  # work of overflowed attempts is not counted
         assert cnt[k] == ccnt[k], k
+
+
+def test_geometry_buffers_match_oracle(emu):
+    """rt_framebuffer depth / normal / albedo of the first sample's primary hit (RenderImage::zbuffer, renderer.h:39; the
+    guide images of the Denoise(color, albedo, normal) overload, denoiser.h:16-17)."""
+    common_checks.check_geometry_buffers(emu, Scene.load(scene_path("c2_mesh_room.xml")), 96, 54)
+    common_checks.check_geometry_buffers(emu, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 96, 54)

@@ -3,8 +3,10 @@ import numpy as np
 import pytest
 
 import oracle_ffi
-from common import params, psnr8, rel_colour_diff
-from conftest import scene_path
+import os
+
+from common import check_geometry_buffers, params, psnr8, rel_colour_diff
+from conftest import ROOT, scene_path
 from raytracer_amd import Scene
 
 pytestmark = pytest.mark.gpu
@@ -70,3 +72,9 @@ def test_sample_ranges_sum_to_full_render(gpu_renderer):
     split = gpu_renderer.resolve(p, acc.data_ptr())
     assert np.allclose(split.radiance[..., :3], full.radiance[..., :3], rtol=1e-5, atol=1e-6)
     assert (split.radiance[..., 3] == 8).all()
+
+
+def test_geometry_buffers_match_oracle(gpu_renderer):
+    """rt_framebuffer depth / normal / albedo (RenderImage::zbuffer, renderer.h:39; Denoise guides, denoiser.h:16-17)."""
+    check_geometry_buffers(gpu_renderer, Scene.load(scene_path("c2_mesh_room.xml")), 480, 270)
+    check_geometry_buffers(gpu_renderer, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 480, 270)
