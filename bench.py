@@ -66,6 +66,42 @@ def _stress():
     return Scene.stress(seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160)
 
 
+def sphere_field_xml(n=2944, seed=11, width=1920, height=1080):
+    """A seeded stand-in for the reference's scenes/volumetric_spiral.xml (2 944 glass spheres under one group node + a
+    floor sphere, one size-0 point light): the scene-graph stress case, Theta(nodes) per ray in the reference."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    mats = ["glassClear", "glassRed", "glassBlue", "glassGold"]
+    out = ['<xml><scene>', '<object type="sphere" name="floor" material="floorMat"><scale value="200"/><translate z="-200"/></object>',
+           '<object name="helix">']
+    for i in range(n):
+        t = i / max(n - 1, 1)
+        ang = 40.0 * t * 2.0 * np.pi
+        rad = 12.0 + 30.0 * t + rng.normal() * 3.0
+        x, y, z = rad * np.cos(ang) + rng.normal() * 2.0, 30.0 + 320.0 * t + rad * np.sin(ang) * 0.3, 1.0 + 40.0 * t + abs(rng.normal()) * 6.0
+        sc = 1.5 + 3.0 * rng.random()
+        out.append(f'<object type="sphere" name="s{i}" material="{mats[int(rng.integers(0, 4))]}"><scale value="{sc:.4f}"/>'
+                   f'<translate x="{x:.4f}" y="{y:.4f}" z="{z:.4f}"/></object>')
+    out.append('</object>')
+    out.append('<material type="blinn" name="floorMat"><diffuse r="0.35" g="0.35" b="0.4"/><specular value="0.2"/><glossiness value="30"/></material>')
+    for name, kd, ab in (("glassClear", "0.05 0.05 0.05", "0.002 0.002 0.002"), ("glassRed", "0.12 0.03 0.03", "0.002 0.01 0.01"),
+                         ("glassBlue", "0.03 0.05 0.12", "0.01 0.008 0.002"), ("glassGold", "0.12 0.09 0.03", "0.01 0.008 0.002")):
+        r, g, b = kd.split()
+        ar, ag, ab_ = ab.split()
+        out.append(f'<material type="blinn" name="{name}"><diffuse r="{r}" g="{g}" b="{b}"/><specular value="0.9"/><glossiness value="95"/>'
+                   f'<refraction value="1.0" index="1.52"/><reflection value="0.3"/><absorption r="{ar}" g="{ag}" b="{ab_}"/></material>')
+    out.append('<light type="ambient"><intensity value="0.12"/></light>')
+    out.append('<light type="point"><intensity value="1.1"/><position x="0" y="0" z="444"/></light>')
+    out.append(f'</scene><camera><position x="0" y="-25" z="12"/><target x="0" y="200" z="30"/><up x="0" y="0" z="1"/><fov value="55"/>'
+               f'<width value="{width}"/><height value="{height}"/></camera></xml>')
+    return "\n".join(out)
+
+
+def _sphere_field():
+    from raytracer_amd import Scene
+    return Scene.from_string(sphere_field_xml())
+
+
 def _c1(p):
     p.pixel_jitter, p.max_bounces, p.light_size_scale = 0, 0, 0.0
 
@@ -89,6 +125,9 @@ CONFIGS = {
                  _load("scenes/c3_cornell_textured.xml"), _c3, cpu_tile_stride=16),
     "c4": Config("c4", "C4: Cornell box (tests/golden/scenes/cornell_box.xml), 2 x 100k photons rebuilt every step, k=128 r=3 gather, "
                  "soft shadows, 3 bounces", 1920, 1080, 8, _load("tests/golden/scenes/cornell_box.xml"), _c4, cpu_tile_stride=8),
+    "spheres": Config("spheres", "scene-graph stress (stand-in for the reference's scenes/volumetric_spiral.xml): 2944 glass spheres under "
+                      "one group node + floor sphere, point light of size 0, 3 bounces reflection + refraction", 1920, 1080, 4, _sphere_field,
+                      lambda p: None, cpu_tile_stride=16),
     "c5": Config("c5", "C5: synthetic stress scene, 12.6 M triangles in one BVH (2048 icospheres + displaced ground), 2 sphere "
                  "lights, 3 bounces; 4 of the 4096 spp per step", 3840, 2160, 4, _stress, lambda p: None, cpu_tile_stride=509),
 }

@@ -103,7 +103,11 @@ struct DScene {
   DTexColor background, environment;
   const int32_t* minst;  // indices (into inst) of the mesh instances, depth-first order
   int32_t n_minst;
-  int32_t pad_;
+  int32_t use_tlas;      // the scene has enough instances for the instance BVH below to pay (rt_scene_commit)
+  const float4* tlas;    // BVH over the instances' padded world boxes, 64-byte nodes as DScene::bvh
+  const int32_t* tlas_idx;  // instance indices in leaf order
+  uint32_t tlas_root;
+  uint32_t pad_;
 };
 #define RT_H2 0
 #define RT_H3 128
@@ -621,6 +625,146 @@ RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& 
   }
 }
 
+// ---- instance BVH (TLAS).  RayTracer::TraverseTree tests every node of the scene graph for every ray
+// (RayTracer.cpp:373-435, Theta(nodes) per ray: 2 945 sphere tests per ray in scenes/volumetric_spiral.xml).  An
+// instance whose padded world box the ray misses cannot be hit, so walking a BVH over those boxes (ordered, pruned
+// against the best hit like the mesh walk) leaves the result unchanged; TraverseTree's "first in depth-first order wins
+// an equal t" becomes an explicit compare on the instance index because the walk visits instances in spatial order.
+template <class IP>
+RT_DEV void ray_to_instance_full(IP I, const float* xfbase, V3 o, V3 dir, V3& p, V3& d) {
+  const float* chain = xfbase + I->xf_off;
+  p = o; d = dir;
+  for (int k = 0; k < I->depth; k++) {
+    V3 np = xf_point(chain + 24 * k, p);
+    V3 nd = xf_dir(chain + 24 * k, d);
+    p = np; d = nd;
+  }
+}
+
+template <bool CNT, bool SPLIT>
+RT_DEV void closest_instances_tlas(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, bool& mesh_flag, uint32_t* stk, uint32_t stride,
+                                   Cnt<CNT>& cnt) {
+  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  mesh_flag = false;
+  uint32_t cur = S.tlas_root;
+  int sp = 0;
+  for (;;) {
+    if (cur & RT_LEAF) {
+      uint32_t count = cur & 7u, first = (cur & 0x7fffffffu) >> 3;
+      for (uint32_t s = 0; s < count; s++) {
+        int i = S.tlas_idx[first + s];
+        const DInstance* I = S.inst + i;
+        int prim = I->prim;
+        float tm;
+        if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+        if (prim == 3 && SPLIT) { mesh_flag = true; continue; }
+        V3 p, d;
+        ray_to_instance_full(I, S.xf, o, dir, p, d);
+        cnt.inst();
+        float t;
+        bool front;
+        if (prim == 1) {
+          cnt.sphere();
+          if (sphere_closest(p, d, hitSide, t, front) && (t < B.t || (t == B.t && i < B.inst))) { B.t = t; B.inst = i; B.front = front; }
+        } else if (prim == 2) {
+          cnt.plane();
+          if (plane_closest(p, d, hitSide, t, front) && (t < B.t || (t == B.t && i < B.inst))) { B.t = t; B.inst = i; B.front = front; }
+        } else if (prim == 3) {
+          V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          MeshHit mh;
+          // stack entries above sp belong to the mesh walk; t_bound = B.t keeps every hit that can still tie
+          if (mesh_closest<CNT>(S, S.meshes[I->mesh], p, d, inv, B.t, mh, stk + sp * stride, stride, cnt) &&
+              (mh.t < B.t || (mh.t == B.t && i < B.inst))) {
+            B.t = mh.t; B.inst = i; B.mh = mh;
+          }
+        }
+      }
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    float4 n0 = S.tlas[4 * cur], n1 = S.tlas[4 * cur + 1], n2 = S.tlas[4 * cur + 2], n3 = S.tlas[4 * cur + 3];
+    float tl, tr;
+    cnt.node(2);
+    bool hl = box_test(o, winv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl);
+    bool hr = box_test(o, winv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr);
+    float bound = prune_bound(B.t);
+    hl = hl && tl <= bound;
+    hr = hr && tr <= bound;
+    uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+    if (hl && hr) {
+      bool left_first = tl <= tr;
+      stk[(sp++) * stride] = left_first ? cr : cl;
+      cur = left_first ? cl : cr;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+    }
+  }
+}
+
+template <bool CNT, bool SPLIT>
+RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+  V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  mesh_flag = false;
+  const float bound = prune_bound(t_max);
+  uint32_t cur = S.tlas_root;
+  int sp = 0;
+  for (;;) {
+    if (cur & RT_LEAF) {
+      uint32_t count = cur & 7u, first = (cur & 0x7fffffffu) >> 3;
+      for (uint32_t s = 0; s < count; s++) {
+        int i = S.tlas_idx[first + s];
+        const DInstance* I = S.inst + i;
+        int prim = I->prim;
+        float tm;
+        if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+        if (prim == 3 && SPLIT) { mesh_flag = true; continue; }
+        V3 p, d;
+        ray_to_instance_full(I, S.xf, o, dir, p, d);
+        cnt.inst();
+        bool occ = false;
+        if (prim == 1) {
+          cnt.sphere();
+          occ = sphere_any(p, d, t_max);
+        } else if (prim == 2) {
+          cnt.plane();
+          occ = plane_any(p, d, t_max);
+        } else if (prim == 3) {
+          V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          occ = mesh_any<CNT>(S, S.meshes[I->mesh], p, d, inv, t_max, stk + sp * stride, stride, cnt);
+        }
+        if (occ) return true;
+      }
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    float4 n0 = S.tlas[4 * cur], n1 = S.tlas[4 * cur + 1], n2 = S.tlas[4 * cur + 2], n3 = S.tlas[4 * cur + 3];
+    float tl, tr;
+    cnt.node(2);
+    bool hl = box_test(o, winv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl) && tl <= bound;
+    bool hr = box_test(o, winv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr) && tr <= bound;
+    uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+    if (hl && hr) {
+      stk[(sp++) * stride] = cr;
+      cur = cl;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+    }
+  }
+  return false;
+}
+
 // Hit attributes of the winner (objects.cpp:37-43, 135-138, 303-320), Node::FromNodeCoords back up the chain
 // (scene.h:184-189), then the renderable lights (RayTracer.cpp:413-432).
 RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit) {
@@ -703,7 +847,8 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
   Best B;
   best_init(B);
   bool mesh_flag;
-  closest_instances<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
+  if (S.use_tlas) closest_instances_tlas<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
+  else closest_instances<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
   return finalize_hit(S, o, dir, B, hit);
 }
 
@@ -747,6 +892,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
 template <bool CNT>
 RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   bool mesh_flag;
+  if (S.use_tlas) return any_instances_tlas<CNT, false>(S, o, dir, t_max, mesh_flag, stk, stride, cnt);
   return any_instances<CNT, false>(S, o, dir, t_max, mesh_flag, stk, stride, cnt);
 }
 

@@ -292,7 +292,8 @@ RT_DEV void read_raw(const RayQ& Q, uint32_t idx, Best& B) {
   B.mh.face = Q.rf[idx];
 }
 
-template <bool CNT>
+// TLAS = true: the instance BVH is walked per lane (scenes with many instances) instead of the wave-uniform table loop.
+template <bool CNT, bool TLAS>
 RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
@@ -309,7 +310,8 @@ RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int
         V3 o = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z);
         traced++;
         // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
-        closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
+        if (TLAS) closest_instances_tlas<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
+        else closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
         if (!need_mesh) write_raw(Q, idx, B);
       }
     }
@@ -906,7 +908,7 @@ RT_DEV void soft_shadow_ray(const DScene& S, float4 g0, float4 g2, float4 g3, fl
 }
 
 // Hard shadows: one ray per group (DirectLight, and PointLight of size 0).
-template <bool CNT>
+template <bool CNT, bool TLAS>
 RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
@@ -920,7 +922,8 @@ RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
       float tmax;
       hard_shadow_ray(S, G.g0[g], Pp, d, tmax);
       rays++;
-      bool occ = any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
+      bool occ = TLAS ? any_instances_tlas<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt)
+                      : any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
       if (occ) need_mesh = false;
       else if (!need_mesh) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
     }
@@ -939,7 +942,7 @@ RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
 
 // Soft shadows, phases of PointLight::Illuminate's sample loop: `j0` .. `j0 + nj - 1` of every group (`list` = null:
 // all groups of the queue; else the groups listed, i.e. those not fully lit after the first shadow_min samples).
-template <bool CNT>
+template <bool CNT, bool TLAS>
 RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list, const uint32_t* list_counts, uint32_t j0,
           uint32_t nj, MeshQ MQ) {
   RT_STACK_DECL
@@ -957,7 +960,8 @@ RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_
       float dist;
       soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], G.g4[g], j, Pp, d, dist);
       rays++;
-      bool occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
+      bool occ = TLAS ? any_instances_tlas<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt)
+                      : any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
       if (occ) need_mesh = false;
       else if (!need_mesh) lit = true;
     }

@@ -54,6 +54,9 @@
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 8   // streaming kernels: measured 4 -> 8 blocks per CU: k_shade 5.8 -> 4.8 ms per bench step
 #endif
+#ifndef RT_TLAS_MIN
+#define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
+#endif
 #ifndef RT_TRACE_BLOCKS_PER_CU
 #define RT_TRACE_BLOCKS_PER_CU 4   // traversal kernels: 32 KB LDS stack per block; 1..6 measured, 4 is fastest
 #endif
@@ -268,6 +271,58 @@ struct MeshConv {
   }
 };
 
+// BVH over the instances' padded world boxes (median split of the box centres along their widest axis, leaves of at
+// most 2 instances), written in the 64-byte paired node layout of the mesh BVHs.
+struct TlasBuild {
+  const std::vector<DInstance>& inst;
+  std::vector<float4> nodes;
+  std::vector<int32_t> order;
+  int max_depth = 0;
+  explicit TlasBuild(const std::vector<DInstance>& i) : inst(i) {}
+  void bounds(const int32_t* ids, size_t n, float* lo, float* hi) const {
+    for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+    for (size_t j = 0; j < n; j++)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], inst[ids[j]].wmin[k]);
+        hi[k] = std::max(hi[k], inst[ids[j]].wmax[k]);
+      }
+  }
+  uint32_t build(int32_t* ids, size_t n, int depth) {
+    max_depth = std::max(max_depth, depth);
+    if (n <= 2) {
+      uint32_t first = (uint32_t)order.size();
+      order.insert(order.end(), ids, ids + n);
+      return RT_LEAF | (first << 3) | (uint32_t)n;
+    }
+    float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t j = 0; j < n; j++)
+      for (int k = 0; k < 3; k++) {
+        float c = 0.5f * (inst[ids[j]].wmin[k] + inst[ids[j]].wmax[k]);
+        clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c);
+      }
+    int axis = 0;
+    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    size_t mid = n / 2;
+    std::nth_element(ids, ids + mid, ids + n, [&](int32_t a, int32_t b) {
+      float ca = inst[a].wmin[axis] + inst[a].wmax[axis], cb = inst[b].wmin[axis] + inst[b].wmax[axis];
+      return ca < cb || (ca == cb && a < b);
+    });
+    uint32_t me = (uint32_t)(nodes.size() / 4);
+    nodes.resize(nodes.size() + 4);
+    float llo[3], lhi[3], rlo[3], rhi[3];
+    bounds(ids, mid, llo, lhi);
+    bounds(ids + mid, n - mid, rlo, rhi);
+    uint32_t l = build(ids, mid, depth + 1);
+    uint32_t r = build(ids + mid, n - mid, depth + 1);
+    nodes[4 * (size_t)me + 0] = make_float4(llo[0], rlo[0], lhi[0], rhi[0]);
+    nodes[4 * (size_t)me + 1] = make_float4(llo[1], rlo[1], lhi[1], rhi[1]);
+    nodes[4 * (size_t)me + 2] = make_float4(llo[2], rlo[2], lhi[2], rhi[2]);
+    nodes[4 * (size_t)me + 3] = make_float4(host_u2f(l), host_u2f(r), 0.0f, 0.0f);
+    return me;
+  }
+};
+
 int fail(rt_context* ctx, int code, const std::string& msg) {
   ctx->err = msg;
   return code;
@@ -422,6 +477,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
 
   // ---- meshes
   std::vector<DMesh> meshes(sc->n_meshes);
+  int max_mesh_depth = 0;
   std::vector<float4> bvh, tris;
   std::vector<float> normals, uvw;
   std::vector<uint32_t> nidx, uidx;
@@ -438,6 +494,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     MeshConv cv(m, bvh, tris);
     uint32_t root;
     if (!cv.convert(0, 0, root)) return fail(ctx, RT_ERR_INVALID, "mesh BVH: " + cv.err);
+    max_mesh_depth = std::max(max_mesh_depth, cv.max_depth);
     D.node_base = (uint32_t)cv.node_base;
     D.tri_base = (uint32_t)cv.tri_base;
     D.root_ref = root;
@@ -538,6 +595,23 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if ((rc = upload(ctx, ctx->scene_mem, minst, &D.minst))) return rc;
   D.n_minst = (int32_t)minst.size();
   ctx->n_minst = D.n_minst;
+  // instance BVH: pays once the wave-uniform table loop is longer than a short divergent walk; the nested mesh walk of
+  // the one-phase callers (rt_trace_closest / rt_trace_any, photons) shares the per-lane stack with it
+  D.use_tlas = 0;
+  size_t tlas_min = RT_TLAS_MIN;
+  if (const char* e = std::getenv("RT_TLAS_MIN")) tlas_min = (size_t)std::atoll(e);  // developer knob (tests force both paths)
+  if (inst.size() >= tlas_min && inst.size() >= 2) {
+    TlasBuild tb(inst);
+    std::vector<int32_t> ids(inst.size());
+    for (size_t i = 0; i < ids.size(); i++) ids[i] = (int32_t)i;
+    uint32_t root = tb.build(ids.data(), ids.size(), 0);
+    if (tb.max_depth + 1 + max_mesh_depth + 1 <= RT_STACK) {
+      if ((rc = upload(ctx, ctx->scene_mem, tb.nodes, &D.tlas))) return rc;
+      if ((rc = upload(ctx, ctx->scene_mem, tb.order, &D.tlas_idx))) return rc;
+      D.tlas_root = root;
+      D.use_tlas = 1;
+    }
+  }
   D.n_inst = (int)inst.size();
   D.n_lights = (int)lights.size();
   D.n_materials = (int)sc->n_materials;
@@ -1144,7 +1218,8 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     {
       MeshQ MQ = meshq(ctx->MQ, CNT_MQ, CUR_MQ);
       Timer t(ctx, RT_K_TRACE_CLOSEST);
-      LAUNCH_P1(k_trace_closest<CNT>, ubn, ctx->ds, P, F, Qc, MQ, lvl);
+      if (ctx->ds.use_tlas) LAUNCH_T((k_trace_closest<CNT, true>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+      else LAUNCH_P1((k_trace_closest<CNT, false>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
       if (meshes) {
         Timer t2(ctx, RT_K_TRACE_MESH);
@@ -1161,7 +1236,8 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       Timer t(ctx, RT_K_SHADOW);
       MeshQ MH = meshq(ctx->MH, CNT_MH, CUR_MH);
       uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
-      LAUNCH_P1(k_shadow_hard<CNT>, gh_ub, ctx->ds, P, F, GH, MH);
+      if (ctx->ds.use_tlas) LAUNCH_T((k_shadow_hard<CNT, true>), gh_ub, ctx->ds, P, F, GH, MH);
+      else LAUNCH_P1((k_shadow_hard<CNT, false>), gh_ub, ctx->ds, P, F, GH, MH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
       if (meshes) {
         Timer t2(ctx, RT_K_SHADOW_MESH);
@@ -1175,8 +1251,12 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
       {
         Timer t(ctx, RT_K_SHADOW);
-        LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
-                  (uint32_t)P.shadow_min, MS1);
+        if (ctx->ds.use_tlas)
+          LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+                   (uint32_t)P.shadow_min, MS1);
+        else
+          LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+                    (uint32_t)P.shadow_min, MS1);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
       }
       if (meshes) {
@@ -1189,8 +1269,12 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
         uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
         {
           Timer t(ctx, RT_K_SHADOW);
-          LAUNCH_P1(k_shadow_soft<CNT>, gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
-                    (uint32_t)P.shadow_min, nr, MS2);
+          if (ctx->ds.use_tlas)
+            LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
+                     (uint32_t)P.shadow_min, nr, MS2);
+          else
+            LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
+                      (uint32_t)P.shadow_min, nr, MS2);
           t.stop((uint64_t)(lvl * CNT_KINDS + CNT_N2));
         }
         if (meshes) {

@@ -74,3 +74,44 @@ def check_geometry_buffers(r, scene, w, h):
     assert np.abs(g.albedo - c.albedo).max() <= 1e-6
     surf = c.hit_node >= 0
     assert np.allclose(np.linalg.norm(c.normal[surf], axis=1), 1.0, atol=1e-5)
+
+
+def check_instance_bvh(r, monkeypatch, scene_path_fn):
+    """The instance BVH (TLAS) against the oracle's Theta(nodes) scene-graph walk (RayTracer.cpp:373-435): a field of
+    overlapping spheres (equal-t ties are decided by depth-first order) and, with the threshold forced down, the
+    stock scenes including mesh instances — frames through the two-phase kernels, batched queries through the
+    one-phase walk with its nested mesh walk."""
+    import sys
+    import oracle_ffi
+    from raytracer_amd import RT_HIT_FRONT_AND_BACK, Scene
+    import bench
+    field = Scene.from_string(bench.sphere_field_xml(n=400, seed=3, width=192, height=108))
+    r.LoadScene(field)
+    orc = oracle_ffi.OracleScene(field)
+    p = params(192, 108, spp=1, jitter=0, bounces=0)
+    g, c = r.Render(p), orc.render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and rel_colour_diff(g.radiance, c.radiance) <= 1e-4
+    assert len(np.unique(c.hit_node)) > 40
+    p = params(96, 54, spp=2, jitter=1, bounces=3)
+    g, c = r.Render(p), orc.render(p)
+    assert psnr8(g.img, c.img) >= 40.0 and np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean() <= 1e-3
+    rays = random_rays(4000, seed=21, origin_box=((-60, -40, 0), (60, 380, 80)), target_box=((-50, 0, 0), (50, 360, 60)))
+    assert_hits_equal(r.TraceRay(rays, RT_HIT_FRONT_AND_BACK), orc.trace_closest(rays, RT_HIT_FRONT_AND_BACK), "sphere field")
+    tmax = np.full(len(rays), 0.8, np.float32)
+    assert np.array_equal(r.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax))
+    monkeypatch.setenv("RT_TLAS_MIN", "2")
+    for name in ("spheres_room.xml", "cornell_box.xml", "c2_mesh_room.xml"):
+        scene = Scene.load(scene_path_fn(name))
+        r.LoadScene(scene)
+        orc = oracle_ffi.OracleScene(scene)
+        p = params(160, 90, spp=1, jitter=0, bounces=0)
+        g, c = r.Render(p), orc.render(p)
+        assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face), name
+        assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4, name
+        rays = random_rays(3000, seed=31)
+        assert_hits_equal(r.TraceRay(rays, RT_HIT_FRONT_AND_BACK), orc.trace_closest(rays, RT_HIT_FRONT_AND_BACK), name)
+        tmax = np.full(len(rays), 1.5, np.float32)
+        assert np.array_equal(r.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax)), name
+        p = params(96, 54, spp=2, jitter=1, bounces=2)
+        g, c = r.Render(p), orc.render(p)
+        assert psnr8(g.img, c.img) >= 40.0, name

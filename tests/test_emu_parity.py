@@ -196,3 +196,7 @@ def test_geometry_buffers_match_oracle(emu):
     guide images of the Denoise(color, albedo, normal) overload, denoiser.h:16-17)."""
     common_checks.check_geometry_buffers(emu, Scene.load(scene_path("c2_mesh_room.xml")), 96, 54)
     common_checks.check_geometry_buffers(emu, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 96, 54)
+
+
+def test_instance_bvh_matches_scene_graph_walk(emu, monkeypatch):
+    common_checks.check_instance_bvh(emu, monkeypatch, scene_path)

@@ -5,7 +5,7 @@ import pytest
 import oracle_ffi
 import os
 
-from common import check_geometry_buffers, params, psnr8, rel_colour_diff
+from common import check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
 from conftest import ROOT, scene_path
 from raytracer_amd import Scene
 
@@ -78,3 +78,7 @@ def test_geometry_buffers_match_oracle(gpu_renderer):
     """rt_framebuffer depth / normal / albedo (RenderImage::zbuffer, renderer.h:39; Denoise guides, denoiser.h:16-17)."""
     check_geometry_buffers(gpu_renderer, Scene.load(scene_path("c2_mesh_room.xml")), 480, 270)
     check_geometry_buffers(gpu_renderer, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 480, 270)
+
+
+def test_instance_bvh_matches_scene_graph_walk(gpu_renderer, monkeypatch):
+    check_instance_bvh(gpu_renderer, monkeypatch, scene_path)
