@@ -115,3 +115,48 @@ def check_instance_bvh(r, monkeypatch, scene_path_fn):
         p = params(96, 54, spp=2, jitter=1, bounces=2)
         g, c = r.Render(p), orc.render(p)
         assert psnr8(g.img, c.img) >= 40.0, name
+
+
+EMPTY_SCENE = """<xml><scene><background r="0.25" g="0.5" b="0.75"/>
+<light type="point"><intensity value="10"/><position x="0" y="0" z="5"/></light></scene>
+<camera><position x="0" y="-10" z="0"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="40"/>
+<width value="40"/><height value="30"/></camera></xml>"""
+
+UNLIT_SCENE = """<xml><scene>
+<object type="sphere" name="a" material="m"><scale value="2"/></object>
+<object type="plane" name="p"><scale value="30"/><translate z="-2"/></object>
+<material type="blinn" name="m"><diffuse value="0.8"/><emission r="0.1" g="0.2" b="0.3"/></material>
+</scene><camera><position x="0" y="-10" z="1"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="40"/>
+<width value="40"/><height value="30"/></camera></xml>"""
+
+
+def check_edge_cases(r):
+    """Empty scene, scene without lights, a default-material node, ragged image sizes (partial 32x32 tiles,
+    partial 64-path wave tiles), 1x1 image, empty ray batches."""
+    import oracle_ffi
+    from raytracer_amd import Scene
+    empty = Scene.from_string(EMPTY_SCENE)
+    r.LoadScene(empty)
+    for w, h in ((40, 30), (1, 1), (33, 17), (65, 3)):
+        p = params(w, h, spp=2, jitter=1, bounces=2)
+        g = r.Render(p)
+        assert (g.hit_node == -1).all() and (g.sample_count == 2).all()
+        assert np.allclose(g.radiance[..., :3], [0.25, 0.5, 0.75], atol=1e-6)
+        assert (g.zbuffer > 1e30).all() and np.allclose(g.albedo, [0.25, 0.5, 0.75], atol=1e-6)
+    assert len(r.TraceRay(random_rays(0, 1))) == 0
+    assert len(r.TraceShadowRay(random_rays(0, 1), np.zeros(0, np.float32))) == 0
+    hits = r.TraceRay(random_rays(100, 2))
+    assert (hits["node"] == -1).all() and (hits["light"] == -1).all()
+    unlit = Scene.from_string(UNLIT_SCENE)
+    r.LoadScene(unlit)
+    orc = oracle_ffi.OracleScene(unlit)
+    for w, h in ((40, 30), (33, 17), (7, 129)):
+        p = params(w, h, spp=3, jitter=1, bounces=2)
+        g, c = r.Render(p), orc.render(p)
+        assert np.array_equal(g.hit_node, c.hit_node)
+        assert np.allclose(g.radiance, c.radiance, rtol=1e-5, atol=1e-6)
+        on_sphere = c.hit_node == 1
+        interior = np.isclose(c.radiance[on_sphere][:, :3], [0.1, 0.2, 0.3], atol=1e-6).all(axis=1)           # emission only
+        assert on_sphere.any() and interior.mean() > 0.6   # (silhouette pixels: some samples miss the sphere)
+        dark = (np.abs(c.radiance[c.hit_node == 2][:, :3]) <= 1e-7).all(axis=1)                                # default Blinn, no light
+        assert dark.mean() > 0.9

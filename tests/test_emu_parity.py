@@ -200,3 +200,7 @@ def test_geometry_buffers_match_oracle(emu):
 
 def test_instance_bvh_matches_scene_graph_walk(emu, monkeypatch):
     common_checks.check_instance_bvh(emu, monkeypatch, scene_path)
+
+
+def test_edge_cases(emu):
+    common_checks.check_edge_cases(emu)
