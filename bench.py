@@ -133,7 +133,7 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cfg, scene, target_seconds=12.0):
+def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
     """The CPU oracle (reference-structured restatement: Θ(nodes) scene-graph walk, BVH visiting both children, std::thread
     over 32x32 tiles) timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -147,18 +147,32 @@ def cpu_baseline(cfg, scene, target_seconds=12.0):
         orc.photons_build(p)   # (outside the timed region: the GPU side's ray count excludes photon rays as well)
     p.sample_count = 1
     t0 = time.perf_counter()
-    _, cnt = orc.render(p, cores, want_counters=True)
+    cpu_img, cnt = orc.render(p, cores, want_counters=True)
     t1 = time.perf_counter() - t0
     spp, dt = 1, t1
     if t1 < 0.5 * target_seconds:
         spp = int(max(1, min(8 * SPP_PER_STEP, target_seconds / max(t1, 1e-3))))
         p.sample_count = spp
         t0 = time.perf_counter()
-        _, cnt = orc.render(p, cores, want_counters=True)
+        cpu_img, cnt = orc.render(p, cores, want_counters=True)
         dt = time.perf_counter() - t0
+    # the same pixels and samples on the GPU: PSNR of the 8-bit images and mean radiance difference (BASELINE metric)
+    import numpy as np
+    if p.photons:   # the comparison isolates rendering: the oracle gathers from the device's photons
+        renderer.BuildPhotonMaps(p)
+        orc.photons_set(0, renderer.GetPhotonMap())
+        orc.photons_set(1, renderer.GetCausticsMap())
+        cpu_img = orc.render(p, cores)
+    g = renderer.Render(p)
+    covered = cpu_img.sample_count > 0
+    d = g.img[covered].astype(np.float64) - cpu_img.img[covered].astype(np.float64)
+    mse = float((d * d).mean())
+    psnr = 99.0 if mse == 0 else 10.0 * float(np.log10(255.0 * 255.0 / mse))
+    mean_abs = float(np.abs(g.radiance[covered][:, :3] - cpu_img.radiance[covered][:, :3]).mean())
     rays = cnt["rays_primary"] + cnt["rays_secondary"] + cnt["rays_shadow"]
     tiles = "all 32x32 tiles" if cfg.cpu_tile_stride == 1 else f"every {cfg.cpu_tile_stride}th 32x32 tile"
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "psnr_gpu_vs_cpu_db": psnr, "mean_abs_radiance_diff": mean_abs, "pixels_compared": int(covered.sum()),
             "sample": f"{WIDTH}x{HEIGHT}, {tiles}, {spp} spp of the same scene/params, {rays} rays in {dt:.2f} s, oracle/liboracle.so "
                       f"(reference structure: no TLAS, BVH visits both children, kd-tree + heap photon gather), {cores} threads"}
 
@@ -316,7 +330,7 @@ def main():
                                  "the kernel is latency / VALU bound rather than HBM bound, so the FP32 VALU fraction is reported beside it"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, scene)
+            out["cpu_baseline"] = cpu_baseline(cfg, scene, r)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
