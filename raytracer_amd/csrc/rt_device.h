@@ -596,13 +596,14 @@ RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& 
   ParentRay pr;
   pr.key = -2; pr.p = o; pr.d = dir;
   mesh_flag = false;
+  float mesh_tmin = RT_BIG;  // nearest entry into a mesh instance's world box
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     int prim = I->prim;
     if (prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
       float tm;       // hit the mesh, so the result is unchanged)
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
-      if (SPLIT) { mesh_flag = true; continue; }
+      if (SPLIT) { mesh_flag = true; mesh_tmin = tm < mesh_tmin ? tm : mesh_tmin; continue; }
     }
     V3 p, d;
     ray_to_instance(I, xf, o, dir, pr, p, d);
@@ -623,6 +624,8 @@ RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& 
       }
     }
   }
+  // every mesh box is entered beyond the sphere / plane hit already found: no mesh can win, the second phase is skipped
+  if (SPLIT && mesh_flag && mesh_tmin > prune_bound(B.t)) mesh_flag = false;
 }
 
 // ---- instance BVH (TLAS).  RayTracer::TraverseTree tests every node of the scene graph for every ray
@@ -723,6 +726,7 @@ RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, bool&
         int prim = I->prim;
         float tm;
         if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+        if (prim == 3 && tm > prune_bound(t_max)) continue;  // the box begins beyond the light
         if (prim == 3 && SPLIT) { mesh_flag = true; continue; }
         V3 p, d;
         ray_to_instance_full(I, S.xf, o, dir, p, d);
@@ -873,6 +877,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
     if (prim == 3) {
       float tm;
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
+      if (tm > prune_bound(t_max)) continue;  // the box begins beyond the light: nothing in it can occlude
       if (SPLIT) { mesh_flag = true; continue; }
     }
     cnt.inst();
@@ -917,12 +922,13 @@ RT_DEV bool ref_is_leaf(uint32_t r) { return (r & RT_LEAF) && r != RT_NOREF; }
 // Advances to the next mesh instance whose padded world box and root box the ray hits; false when there is none left.
 // Same tests, in the same order, as closest_instances / any_instances make for a mesh instance.
 template <bool CNT>
-RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, MeshWalk& W, Cnt<CNT>& cnt) {
+RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, float t_limit, MeshWalk& W, Cnt<CNT>& cnt) {
   while (W.mi < S.n_minst) {
     int ii = S.minst[W.mi++];
     const DInstance& I = S.inst[ii];
     float tm;
     if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    if (tm > prune_bound(t_limit)) continue;  // entered beyond the best hit so far / the light: cannot matter
     const float* chain = S.xf + I.xf_off;
     V3 p = o, d = dir;
     for (int k = 0; k < I.depth; k++) {

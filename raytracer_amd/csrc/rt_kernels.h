@@ -466,7 +466,7 @@ RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int le
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
       if (state == RT_ST_NEXT) {
-        if (mesh_walk_next<CNT>(S, o, dir, winv, W, cnt)) {
+        if (mesh_walk_next<CNT>(S, o, dir, winv, B.t, W, cnt)) {
           L.t = RT_BIG; lfound = false;
           state = RT_ST_WALK;
         } else {
@@ -1028,7 +1028,7 @@ RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
-      if (state == RT_ST_NEXT) state = mesh_walk_next<CNT>(S, o, dir, winv, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
+      if (state == RT_ST_NEXT) state = mesh_walk_next<CNT>(S, o, dir, winv, tmax, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
       continue;
     }
     if (n_node != 0 && (n_pend < RT_LEAF_MIN || n_node >= RT_WAVE / 2) && (n_node >= RT_NODE_MIN || n_pend < RT_NODE_MIN)) {
