@@ -459,8 +459,11 @@ struct GatherP {
 };
 
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
+#ifndef RT_GATHER_WAVES
+#define RT_GATHER_WAVES 4
+#endif
 template <bool CNT>
-RT_KERNEL(k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
+RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
   RT_HEAP_DECL(G.depth)
   uint32_t visits = 0, gathers = 0;
   float guess[2] = {0.0f, 0.0f};  // per map: the squared radius the lane's previous lookup needed

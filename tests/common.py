@@ -160,3 +160,81 @@ def check_edge_cases(r):
         assert on_sphere.any() and interior.mean() > 0.6   # (silhouette pixels: some samples miss the sphere)
         dark = (np.abs(c.radiance[c.hit_node == 2][:, :3]) <= 1e-7).all(axis=1)                                # default Blinn, no light
         assert dark.mean() > 0.9
+
+
+def random_scene_xml(seed, n_objects=14, width=96, height=64):
+    """A seeded random scene graph: spheres, planes and small procedural meshes under nested nodes (up to 4 levels) with
+    non-uniform scales, rotations about arbitrary axes and translations in document order (xmlload.cpp:176-198),
+    overlapping on purpose (equal-t ties, objects inside objects), mixed materials, one point and one direct light."""
+    rng = np.random.default_rng(seed)
+    kinds = ['sphere', 'sphere', 'plane', 'obj']
+
+    def xform(scale_lo, scale_hi, spread):
+        parts = []
+        for _ in range(int(rng.integers(1, 4))):
+            c = int(rng.integers(0, 3))
+            if c == 0:
+                if rng.random() < 0.5:
+                    parts.append(f'<scale value="{rng.uniform(scale_lo, scale_hi):.4f}"/>')
+                else:
+                    parts.append(f'<scale x="{rng.uniform(scale_lo, scale_hi):.4f}" y="{rng.uniform(scale_lo, scale_hi):.4f}" z="{rng.uniform(scale_lo, scale_hi):.4f}"/>')
+            elif c == 1:
+                a = rng.normal(size=3)
+                parts.append(f'<rotate angle="{rng.uniform(-180, 180):.3f}" x="{a[0]:.4f}" y="{a[1]:.4f}" z="{a[2]:.4f}"/>')
+            else:
+                t = rng.uniform(-spread, spread, size=3)
+                parts.append(f'<translate x="{t[0]:.4f}" y="{t[1]:.4f}" z="{t[2]:.4f}"/>')
+        return "".join(parts)
+
+    def obj(i, depth):
+        k = kinds[int(rng.integers(0, len(kinds)))]
+        name = f'gen:icosphere?seed={i}&amp;tris=320' if k == 'obj' else f'o{i}'
+        children = ""
+        if depth < 3 and rng.random() < 0.45:
+            children = "".join(obj(i * 7 + j + 100, depth + 1) for j in range(int(rng.integers(1, 3))))
+        mat = ['m0', 'm1', 'm2', 'm3'][int(rng.integers(0, 4))]
+        return f'<object type="{k}" name="{name}" material="{mat}">{xform(0.6, 3.0, 5.0)}{children}</object>'
+
+    body = "".join(obj(i, 0) for i in range(n_objects))
+    return f"""<xml><scene>{body}
+<object name="grp">{xform(0.8, 1.5, 3.0)}<object type="plane" name="floor" material="m0"><scale value="25"/><translate z="-6"/></object></object>
+<material type="blinn" name="m0"><diffuse r="0.7" g="0.6" b="0.5"/><specular value="0.3"/><glossiness value="30"/></material>
+<material type="blinn" name="m1"><diffuse value="0.1"/><specular value="0.8"/><glossiness value="60"/><reflection value="0.7"/></material>
+<material type="blinn" name="m2"><diffuse value="0.05"/><specular value="0.5"/><glossiness value="80"/><refraction value="0.9" index="1.45"/><absorption r="0.02" g="0.05" b="0.01"/></material>
+<material type="phong" name="m3"/>
+<light type="point"><intensity value="80"/><position x="3" y="-6" z="12"/><attenuation value="1"/></light>
+<light type="direct"><intensity value="0.4"/><direction x="-1" y="2" z="-3"/></light>
+<background r="0.1" g="0.1" b="0.2"/>
+</scene><camera><position x="0" y="-26" z="6"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="42"/>
+<width value="{width}"/><height value="{height}"/></camera></xml>"""
+
+
+def check_random_scene_graphs(r, seeds, n_rays, w, h):
+    """Bit-exact decisions on randomly nested, transformed, overlapping scene graphs: batched closest / any-hit queries
+    and a deterministic frame, with the linear instance walk and with the instance BVH."""
+    import os
+    import oracle_ffi
+    from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, Scene
+    for seed in seeds:
+        xml = random_scene_xml(seed, width=w, height=h)
+        for tlas_min in ("1000000", "2"):
+            os.environ["RT_TLAS_MIN"] = tlas_min
+            try:
+                scene = Scene.from_string(xml)
+                r.LoadScene(scene)
+            finally:
+                del os.environ["RT_TLAS_MIN"]
+            orc = oracle_ffi.OracleScene(scene)
+            rays = random_rays(n_rays, seed=100 + seed, origin_box=((-20, -30, -8), (20, 20, 16)), target_box=((-8, -8, -6), (8, 8, 8)))
+            for side in (RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK):
+                assert_hits_equal(r.TraceRay(rays, side), orc.trace_closest(rays, side), f"seed {seed} tlas_min {tlas_min} side {side}")
+            tmax = np.full(len(rays), 1.2, np.float32)
+            tmax[::5] = np.finfo(np.float32).max
+            assert np.array_equal(r.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax)), f"seed {seed}: occlusion differs"
+            p = params(w, h, spp=1, jitter=0, bounces=0)
+            g, c = r.Render(p), orc.render(p)
+            assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face), f"seed {seed}: hit ids differ"
+            assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4, f"seed {seed}"
+            p = params(w // 2, h // 2, spp=2, jitter=1, bounces=3)
+            g, c = r.Render(p), orc.render(p)
+            assert psnr8(g.img, c.img) >= 40.0, f"seed {seed}: PSNR {psnr8(g.img, c.img)}"

@@ -204,3 +204,7 @@ def test_instance_bvh_matches_scene_graph_walk(emu, monkeypatch):
 
 def test_edge_cases(emu):
     common_checks.check_edge_cases(emu)
+
+
+def test_random_scene_graphs(emu):
+    common_checks.check_random_scene_graphs(emu, seeds=(1, 2, 3), n_rays=1500, w=64, h=48)

@@ -5,7 +5,7 @@ import pytest
 import oracle_ffi
 import os
 
-from common import check_edge_cases, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
+from common import check_edge_cases, check_random_scene_graphs, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
 from conftest import ROOT, scene_path
 from raytracer_amd import Scene
 
@@ -86,3 +86,7 @@ def test_instance_bvh_matches_scene_graph_walk(gpu_renderer, monkeypatch):
 
 def test_edge_cases(gpu_renderer):
     check_edge_cases(gpu_renderer)
+
+
+def test_random_scene_graphs(gpu_renderer):
+    check_random_scene_graphs(gpu_renderer, seeds=(1, 2, 3, 4, 5, 6), n_rays=20000, w=192, h=128)
