@@ -334,6 +334,24 @@ RT_DEV void box_test_fast2(V3 p, V3 inv, float4 nx, float4 ny, float4 nz, bool& 
   hl = tmaxl >= tminl && tmaxl >= 0.0f;
   hr = tmaxr >= tminr && tmaxr >= 0.0f;
 }
+// The walk's form of the same two tests with the pruning bound folded in: a child is entered iff
+// tmax >= tmin && tmax >= 0 && tmin <= bound, i.e. iff min(tmax, bound) >= max(tmin, 0) (bound >= 0).  `tl`, `tr` return
+// max(tmin, 0), which orders the children exactly as tmin does except that two boxes the origin lies in tie.
+RT_DEV void box_test_walk2(V3 p, V3 inv, float4 nx, float4 ny, float4 nz, float bound, bool& hl, bool& hr, float& tl, float& tr) {
+  float t1l = (nx.x - p.x) * inv.x, t1r = (nx.y - p.x) * inv.x;
+  float t2l = (nx.z - p.x) * inv.x, t2r = (nx.w - p.x) * inv.x;
+  float t3l = (ny.x - p.y) * inv.y, t3r = (ny.y - p.y) * inv.y;
+  float t4l = (ny.z - p.y) * inv.y, t4r = (ny.w - p.y) * inv.y;
+  float t5l = (nz.x - p.z) * inv.z, t5r = (nz.y - p.z) * inv.z;
+  float t6l = (nz.z - p.z) * inv.z, t6r = (nz.w - p.z) * inv.z;
+  float tminl = fmaxf(fmaxf(fmaxf(fminf(t1l, t2l), fminf(t3l, t4l)), fminf(t5l, t6l)), 0.0f);
+  float tminr = fmaxf(fmaxf(fmaxf(fminf(t1r, t2r), fminf(t3r, t4r)), fminf(t5r, t6r)), 0.0f);
+  float tmaxl = fminf(fminf(fminf(fmaxf(t1l, t2l), fmaxf(t3l, t4l)), fmaxf(t5l, t6l)), bound);
+  float tmaxr = fminf(fminf(fminf(fmaxf(t1r, t2r), fmaxf(t3r, t4r)), fmaxf(t5r, t6r)), bound);
+  tl = tminl; tr = tminr;
+  hl = tmaxl >= tminl;
+  hr = tmaxr >= tminr;
+}
 template <bool FAST>
 RT_DEV bool box_test_sel(V3 p, V3 inv, float b0, float b1, float b2, float b3, float b4, float b5, float& tmin_out) {
   if (FAST) return box_test_fast(p, inv, b0, b1, b2, b3, b4, b5, tmin_out);
@@ -978,14 +996,12 @@ RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 
   float tl, tr;
   cnt.node(2);
   bool hl, hr;
-  box_test_fast2(W.p, W.inv, n0, n1, n2, hl, hr, tl, tr);
+  const float bound = prune_bound(bound_t);
+  box_test_walk2(W.p, W.inv, n0, n1, n2, bound, hl, hr, tl, tr);
   if (!W.fast) {  // a zero direction component: the literal hitAABB form (NaN behaviour of FAST_MIN / FAST_MAX)
-    hl = box_test(W.p, W.inv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl);
-    hr = box_test(W.p, W.inv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr);
+    hl = box_test(W.p, W.inv, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, tl) && tl <= bound;
+    hr = box_test(W.p, W.inv, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, tr) && tr <= bound;
   }
-  float bound = prune_bound(bound_t);
-  hl = hl && tl <= bound;
-  hr = hr && tr <= bound;
   uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
   bool left_first = ORDERED ? (tl <= tr) : true;
   bool both = hl && hr, any = hl || hr;

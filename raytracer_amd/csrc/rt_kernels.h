@@ -208,7 +208,9 @@ RT_DEV void seg_walk_init(SegWalk& w, uint32_t nseg) {
 RT_DEV float two_pi_times(float x) { return (float)(2.0 * RT_PI_D * (double)x); }  // `2.0f * M_PI * x` promotes to double
 
 #ifndef RT_EMU
-#define RT_STACK_DECL __shared__ uint32_t s_stack[RT_STACK * RT_BLOCK]; uint32_t* stk = s_stack + RT_LANE_IN_BLOCK; const uint32_t stride = RT_BLOCK;
+// per-lane traversal stack in dynamic LDS, [entry][lane]: the launch sizes it to the committed scene's deepest BVH (+ the
+// instance BVH), so shallow scenes leave LDS for more resident blocks (kernels that never push may be launched with none)
+#define RT_STACK_DECL extern __shared__ uint32_t s_stack[]; uint32_t* stk = s_stack + RT_LANE_IN_BLOCK; const uint32_t stride = RT_BLOCK;
 #else
 #define RT_STACK_DECL uint32_t s_stack[RT_STACK]; uint32_t* stk = s_stack; const uint32_t stride = 1;
 #endif
@@ -391,8 +393,11 @@ __device__ unsigned long long g_walk_stats[16];
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 24u     // parked leaves that trigger a leaf step while enough lanes still stand at inner nodes
 #endif
+#ifndef RT_MESH_WAVES
+#define RT_MESH_WAVES 5          // measured with the scene-sized stack: 4 -> 7.24 ms, 5 -> 6.58 ms, 6 -> 7.65 ms (spills) per C2 step
+#endif
 template <bool CNT>
-RT_KERNEL(k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
+RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int level) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
   const uint32_t nseg = MQ.nseg;
@@ -980,8 +985,11 @@ RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_
 }
 
 // Second phase of the shadow kernels: any-hit walk over the mesh instances for the undecided rays.
+#ifndef RT_SHADOW_MESH_WAVES
+#define RT_SHADOW_MESH_WAVES 6   // 4 -> 4.19 ms, 5 -> 3.81 ms, 6 -> 3.59 ms, 8 -> 4.56 ms per C2 step
+#endif
 template <bool CNT, bool SOFT>
-RT_KERNEL(k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
+RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
   const uint32_t nseg = MQ.nseg;

@@ -31,18 +31,19 @@
   } while (0)
 
 #ifndef RT_EMU
-#define LAUNCH_N(kern, n_items, cap_, ...)                                                       \
+#define LAUNCH_NL(kern, n_items, cap_, lds_, ...)                                                \
   do {                                                                                           \
     unsigned long long ni_ = (unsigned long long)(n_items);                                      \
     unsigned long long nb_ = (ni_ + RT_BLOCK - 1) / RT_BLOCK;                                    \
     if (nb_ < 1) nb_ = 1;                                                                        \
     if (nb_ > (unsigned long long)(cap_)) nb_ = (cap_);                                          \
-    hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_BLOCK), 0, ctx->stream, __VA_ARGS__);  \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_BLOCK), (lds_), ctx->stream, __VA_ARGS__); \
   } while (0)
+#define LAUNCH_N(kern, n_items, cap_, ...) LAUNCH_NL(kern, n_items, cap_, 0, __VA_ARGS__)
 // streaming kernels (raygen, shade, accumulate, ...) and traversal kernels (LDS stack, cache-bound) get their own
 // persistent grid sizes
 #define LAUNCH(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
-#define LAUNCH_T(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks_trace, __VA_ARGS__)
+#define LAUNCH_T(kern, n_items, ...) LAUNCH_NL(kern, n_items, ctx->max_blocks_trace, ctx->trace_lds, __VA_ARGS__)
 // first-phase trace kernels (instance table only, no BVH stack): streaming grid (measured: k_trace_closest 2.18 -> 1.92 ms)
 #define LAUNCH_P1(kern, n_items, ...) LAUNCH_N(kern, n_items, ctx->max_blocks, __VA_ARGS__)
 #else
@@ -58,7 +59,7 @@
 #define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
 #endif
 #ifndef RT_TRACE_BLOCKS_PER_CU
-#define RT_TRACE_BLOCKS_PER_CU 4   // traversal kernels: 32 KB LDS stack per block; 1..6 measured, 4 is fastest
+#define RT_TRACE_BLOCKS_PER_CU 6   // traversal kernels: at most this many blocks per CU, fewer when the scene's stack needs the LDS
 #endif
 
 namespace {
@@ -83,6 +84,8 @@ struct rt_context {
   hipStream_t stream = nullptr;
   std::string err;
   int max_blocks = 2048, max_blocks_trace = 1024;
+  int n_cus = 256;
+  size_t trace_lds = (size_t)RT_STACK * RT_BLOCK * 4;   // dynamic LDS of the traversal kernels: stack entries of the scene x block
   bool has_scene = false;
 
   // committed scene (device)
@@ -377,7 +380,8 @@ int rt_context_create(int device_id, rt_context** out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
   {
     ctx->max_blocks = prop.multiProcessorCount * RT_BLOCKS_PER_CU;
-    ctx->max_blocks_trace = prop.multiProcessorCount * RT_TRACE_BLOCKS_PER_CU;  // LDS stack: RT_STACK x 1 KB per block
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->max_blocks_trace = prop.multiProcessorCount * RT_TRACE_BLOCKS_PER_CU;  // re-sized per scene by rt_scene_commit
   }
 #endif
   void* p = nullptr;
@@ -598,6 +602,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   // instance BVH: pays once the wave-uniform table loop is longer than a short divergent walk; the nested mesh walk of
   // the one-phase callers (rt_trace_closest / rt_trace_any, photons) shares the per-lane stack with it
   D.use_tlas = 0;
+  int tlas_depth = 0;
   size_t tlas_min = RT_TLAS_MIN;
   if (const char* e = std::getenv("RT_TLAS_MIN")) tlas_min = (size_t)std::atoll(e);  // developer knob (tests force both paths)
   if (inst.size() >= tlas_min && inst.size() >= 2) {
@@ -610,7 +615,18 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       if ((rc = upload(ctx, ctx->scene_mem, tb.order, &D.tlas_idx))) return rc;
       D.tlas_root = root;
       D.use_tlas = 1;
+      tlas_depth = tb.max_depth;
     }
+  }
+  {  // traversal stack: one entry per BVH level that can hold a deferred sibling (+ the instance BVH's when it is used,
+     // whose one-phase walk nests the mesh walk above its own entries)
+    int entries = max_mesh_depth + 2 + (D.use_tlas ? tlas_depth + 2 : 0);
+    entries = std::max(4, std::min(entries, (int)RT_STACK));
+#ifndef RT_EMU
+    ctx->trace_lds = (size_t)entries * RT_BLOCK * 4;
+    int fit = (int)((160u * 1024u) / ctx->trace_lds);
+    ctx->max_blocks_trace = ctx->n_cus * std::max(1, std::min(fit, (int)RT_TRACE_BLOCKS_PER_CU));
+#endif
   }
   D.n_inst = (int)inst.size();
   D.n_lights = (int)lights.size();
