@@ -405,7 +405,6 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
   const uint32_t refill_min = RT_REFILL_MIN < RT_WAVE ? RT_REFILL_MIN : RT_WAVE;
   int state = RT_ST_IDLE;
   uint32_t ray_idx = 0;
-  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0), winv = v3(0, 0, 0);
   Best B;
   best_init(B);
   MeshWalk W;
@@ -459,9 +458,6 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
         if (wi != RT_NONE) {
           uint4 it = MQ.item4[wi];
           ray_idx = it.x;
-          float4 a = Q.q0[ray_idx], b = Q.q1[ray_idx];
-          o = v3(a.x, a.y, a.z); dir = v3(b.x, b.y, b.z);
-          winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
           best_init(B);
           B.t = __uint_as_float(it.y); B.inst = (int)it.z; B.front = it.w != 0;
           W.mi = 0;
@@ -471,6 +467,11 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
       if (state == RT_ST_NEXT) {
+        // the world-space ray is only needed here: it is re-read from the queue (once per instance entered) instead of
+        // being held in nine registers through the walk — the walk is latency-bound and gains from every wave more
+        float4 a = Q.q0[ray_idx], b = Q.q1[ray_idx];
+        V3 o = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z);
+        V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         if (mesh_walk_next<CNT>(S, o, dir, winv, B.t, W, cnt)) {
           L.t = RT_BIG; lfound = false;
           state = RT_ST_WALK;
@@ -997,7 +998,7 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   const uint32_t refill_min = RT_REFILL_MIN < RT_WAVE ? RT_REFILL_MIN : RT_WAVE;
   int state = RT_ST_IDLE;
   uint32_t group = 0;
-  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0), winv = v3(0, 0, 0);
+  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0);
   float tmax = 0.0f;
   uint32_t guard = 0;
   MeshWalk W;
@@ -1030,13 +1031,15 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
           group = it.x;
           if (SOFT) soft_shadow_ray(S, G.g0[group], G.g2[group], G.g3[group], G.g4[group], it.y, o, dir, tmax);
           else hard_shadow_ray(S, G.g0[group], o, dir, tmax);
-          winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
           W.mi = 0;
           state = RT_ST_NEXT;
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
-      if (state == RT_ST_NEXT) state = mesh_walk_next<CNT>(S, o, dir, winv, tmax, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
+      if (state == RT_ST_NEXT) {
+        V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        state = mesh_walk_next<CNT>(S, o, dir, winv, tmax, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
+      }
       continue;
     }
     if (n_node != 0 && (n_pend < RT_LEAF_MIN || n_node >= RT_WAVE / 2) && (n_node >= RT_NODE_MIN || n_pend < RT_NODE_MIN)) {
