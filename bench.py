@@ -283,9 +283,14 @@ def main():
         sh_nodes = cnt["node_visits"] - cnt["closest_node_visits"]
         sh_tris = cnt["tri_tests"] - cnt["closest_tri_tests"]
         kern = {
-            "k_trace_closest": (prof["trace_closest"], 48.0 * tc_rays + 96.0 * first_inst,
-                                36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
-                                / max(tc_rays + cnt["rays_shadow"], 1)),
+            # first phase of the closest-hit queries: k_raygen_trace (camera rays: 80 B written per path, generated and
+            # traced in registers) + k_trace_closest (secondary rays); the instance BVH's boxes count when it is used
+            "k_raygen_trace+k_trace_closest": (
+                {"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
+                80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"] + 96.0 * first_inst
+                + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
+                36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
+                / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0)),
             "k_trace_mesh": (prof["trace_mesh"],
                              48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"]
                              + 96.0 * cnt["mesh_inst_tests"],

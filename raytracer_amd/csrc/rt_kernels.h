@@ -2,8 +2,9 @@
 //
 // One camera sample = one "path slot".  Stages, each a grid-stride kernel over a device-side queue whose length
 // lives in device memory (no host round trip between stages):
-//   k_raygen         RunThread's camera-ray construction            (RayTracer.cpp:138-174)
-//   k_trace_closest  Renderer::TraceRay for a ray queue             (RayTracer.cpp:373-435, objects.cpp)
+//   k_raygen_trace   RunThread's camera-ray construction + the rays' first trace phase (RayTracer.cpp:138-174, 373-435)
+//   k_trace_closest  Renderer::TraceRay for a queue of secondary rays, first phase; k_trace_mesh: second (BVH) phase
+//                                                                   (RayTracer.cpp:373-435, objects.cpp)
 //   k_shade          SendRay's dispatch + MtlBlinn::Shade + the light loop's unshadowed BRDF terms; appends
 //                    refraction / reflection / indirect rays to the next level's queue and shadow work to the
 //                    shadow queues                                  (RayTracer.cpp:227-259, materials.cpp:222-331)
@@ -216,59 +217,40 @@ RT_DEV float two_pi_times(float x) { return (float)(2.0 * RT_PI_D * (double)x); 
 #endif
 
 // ------------------------------------------------------------------------------------------------ raygen
-RT_KERNEL(k_raygen, DScene S, PassP P, FrameBufs F, RayQ Q) {
-  uint32_t total = P.n_pix * (uint32_t)P.n_samples;
-  for (uint32_t idx = RT_TID; idx < total; idx += RT_NTHREADS) {
-    uint32_t j = idx % P.n_pix, k = idx / P.n_pix;
-    uint32_t pixel = F.pixels[j];
-    int x = (int)(pixel % (uint32_t)P.W), y = (int)(pixel / (uint32_t)P.W);
-    int i = P.sample_base + (int)k;
-    float hx = 0, hy = 0;
-    V3 camOff = v3(0, 0, 0);
-    if (P.jitter) {
-      uint32_t r[4];
-      philox4x32_10(pixel, 0, 0, RT_TAG_PIXEL, P.seed_lo, P.seed_hi, r);
-      float ro = u32_to_unit(r[0]), roy = u32_to_unit(r[1]);
-      hx = S.halton[RT_H2 + (i & 127)] + ro;   // RayTracer.cpp:138-144 (Y also uses randomOffset)
-      if (hx > 1.0f) hx -= 1.0f;
-      hy = S.halton[RT_H3 + (i & 127)] + ro;
-      if (hy > 1.0f) hy -= 1.0f;
-      float discX = S.halton[RT_H5 + (i & 127)] + ro;   // :152-157
-      float discY = S.halton[RT_H7 + (i & 127)] + roy;
-      if (discX > 1.0f) discX -= 1.0f;
-      if (discY > 1.0f) discY -= 1.0f;
-      float r_ = sqrtf(discX);
-      float angle = two_pi_times(discY);
-      float lensU = r_ * P.dof * cosf(angle);
-      float lensV = r_ * P.dof * sinf(angle);
-      camOff = v3(lensU, lensV, 0.0f);
-    }
-    float pixX = -(P.ww / 2.0f) + ((P.ww * ((float)x + (1.0f / 2.0f) + hx) / P.camW));   // :147
-    float pixY = (P.wh / 2.0f) - ((P.wh * ((float)y + (1.0f / 2.0f) + hy) / P.camH));    // :148
-    V3 pixelPos = v3(pixX, pixY, -P.l);
-    V3 X = v3(P.X[0], P.X[1], P.X[2]), Y = v3(P.Y[0], P.Y[1], P.Y[2]), Z = v3(P.Z[0], P.Z[1], P.Z[2]);
-    V3 worldCamera = X * camOff.x + Y * camOff.y + Z * camOff.z;      // cam2Wrld * (v, 0), :165-166
-    V3 worldPixel = X * pixelPos.x + Y * pixelPos.y + Z * pixelPos.z;
-    V3 origin = v3(P.pos[0], P.pos[1], P.pos[2]) + worldCamera;
-    V3 dir = worldPixel - worldCamera;
-    // 64-path tiles (8x8 pixels of one sample) are dealt round-robin to the queue segments
-    uint32_t tile = idx / 64u;
-    uint32_t qi = (tile % Q.nseg) * Q.segcap + (tile / Q.nseg) * 64u + (idx % 64u);
-    Q.q0[qi] = make_float4(origin.x, origin.y, origin.z, 1.0f);
-    Q.q1[qi] = make_float4(dir.x, dir.y, dir.z, 1.0f);
-    Q.q2[qi] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    uint4 m;
-    m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
-    Q.q3[qi] = m;
-    F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+// Camera ray of path slot `idx` (RayTracer.cpp:138-174).
+RT_DEV void primary_ray(const DScene& S, const PassP& P, const FrameBufs& F, uint32_t idx, V3& origin, V3& dir, uint32_t& pixel, int& i) {
+  uint32_t j = idx % P.n_pix, k = idx / P.n_pix;
+  pixel = F.pixels[j];
+  int x = (int)(pixel % (uint32_t)P.W), y = (int)(pixel / (uint32_t)P.W);
+  i = P.sample_base + (int)k;
+  float hx = 0, hy = 0;
+  V3 camOff = v3(0, 0, 0);
+  if (P.jitter) {
+    uint32_t r[4];
+    philox4x32_10(pixel, 0, 0, RT_TAG_PIXEL, P.seed_lo, P.seed_hi, r);
+    float ro = u32_to_unit(r[0]), roy = u32_to_unit(r[1]);
+    hx = S.halton[RT_H2 + (i & 127)] + ro;   // RayTracer.cpp:138-144 (Y also uses randomOffset)
+    if (hx > 1.0f) hx -= 1.0f;
+    hy = S.halton[RT_H3 + (i & 127)] + ro;
+    if (hy > 1.0f) hy -= 1.0f;
+    float discX = S.halton[RT_H5 + (i & 127)] + ro;   // :152-157
+    float discY = S.halton[RT_H7 + (i & 127)] + roy;
+    if (discX > 1.0f) discX -= 1.0f;
+    if (discY > 1.0f) discY -= 1.0f;
+    float r_ = sqrtf(discX);
+    float angle = two_pi_times(discY);
+    float lensU = r_ * P.dof * cosf(angle);
+    float lensV = r_ * P.dof * sinf(angle);
+    camOff = v3(lensU, lensV, 0.0f);
   }
-  uint32_t tiles = (total + 63u) / 64u;
-  for (uint32_t sgm = RT_TID; sgm < Q.nseg; sgm += RT_NTHREADS) {
-    uint32_t nt = tiles > sgm ? (tiles - sgm + Q.nseg - 1u) / Q.nseg : 0u;
-    uint32_t cnt = nt * 64u;
-    if (nt && (tiles - 1u) % Q.nseg == sgm) cnt -= tiles * 64u - total;  // the last tile may be partial
-    Q.counts[sgm * RT_CSTRIDE] = cnt;
-  }
+  float pixX = -(P.ww / 2.0f) + ((P.ww * ((float)x + (1.0f / 2.0f) + hx) / P.camW));   // :147
+  float pixY = (P.wh / 2.0f) - ((P.wh * ((float)y + (1.0f / 2.0f) + hy) / P.camH));    // :148
+  V3 pixelPos = v3(pixX, pixY, -P.l);
+  V3 X = v3(P.X[0], P.X[1], P.X[2]), Y = v3(P.Y[0], P.Y[1], P.Y[2]), Z = v3(P.Z[0], P.Z[1], P.Z[2]);
+  V3 worldCamera = X * camOff.x + Y * camOff.y + Z * camOff.z;      // cam2Wrld * (v, 0), :165-166
+  V3 worldPixel = X * pixelPos.x + Y * pixelPos.y + Z * pixelPos.z;
+  origin = v3(P.pos[0], P.pos[1], P.pos[2]) + worldCamera;
+  dir = worldPixel - worldCamera;
 }
 
 // ------------------------------------------------------------------------------------------------ trace
@@ -292,6 +274,63 @@ RT_DEV void read_raw(const RayQ& Q, uint32_t idx, Best& B) {
   B.t = r.x; B.mh.u = r.y; B.mh.v = r.z; B.mh.t = r.x; B.mh.key = 0;
   B.inst = (int)(w & 0x7fffffffu) - 1; B.front = (w >> 31) != 0;
   B.mh.face = Q.rf[idx];
+}
+
+// Camera rays and their first phase in one kernel: the ray is generated, written to the level-0 queue (k_shade and
+// k_trace_mesh read it) and taken through the instance table while still in registers (separate kernels re-read 48 bytes
+// per path).  64-path tiles (8x8 pixels of one sample) are dealt round-robin to the queue segments; a wave handles one
+// tile per iteration, so its appends go to that tile's segment.
+template <bool CNT, bool TLAS>
+RT_KERNEL(k_raygen_trace, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ) {
+  RT_STACK_DECL
+  Cnt<CNT> cnt;
+  uint32_t traced = 0;
+  const uint32_t total = P.n_pix * (uint32_t)P.n_samples;
+  for (uint32_t idx = RT_TID; (idx & ~63u) < total; idx += RT_NTHREADS) {
+    const bool valid = idx < total;
+    const uint32_t tile = idx / 64u;
+    const uint32_t seg = tile % Q.nseg;
+    const uint32_t qi = seg * Q.segcap + (tile / Q.nseg) * 64u + (idx % 64u);
+    bool need_mesh = false;
+    Best B;
+    best_init(B);
+    if (valid) {
+      V3 o, dir;
+      uint32_t pixel;
+      int i;
+      primary_ray(S, P, F, idx, o, dir, pixel, i);
+      Q.q0[qi] = make_float4(o.x, o.y, o.z, 1.0f);
+      Q.q1[qi] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+      Q.q2[qi] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+      uint4 m;
+      m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
+      Q.q3[qi] = m;
+      F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      traced++;
+      // primary rays see front faces only (RayTracer.cpp:233)
+      if (TLAS) closest_instances_tlas<CNT, true>(S, o, dir, 1, B, need_mesh, stk, stride, cnt);
+      else closest_instances<CNT, true>(S, o, dir, 1, B, need_mesh, stk, stride, cnt);
+      if (!need_mesh) write_raw(Q, qi, B);
+    }
+    uint32_t wi = seg_push(need_mesh, MQ.counts, seg % MQ.nseg, MQ.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      uint4 it;
+      it.x = qi; it.y = __float_as_uint(B.t); it.z = (uint32_t)B.inst; it.w = B.front ? 1u : 0u;
+      MQ.item4[wi] = it;
+    }
+  }
+  uint32_t tiles = (total + 63u) / 64u;
+  for (uint32_t sgm = RT_TID; sgm < Q.nseg; sgm += RT_NTHREADS) {
+    uint32_t nt = tiles > sgm ? (tiles - sgm + Q.nseg - 1u) / Q.nseg : 0u;
+    uint32_t c = nt * 64u;
+    if (nt && (tiles - 1u) % Q.nseg == sgm) c -= tiles * 64u - total;  // the last tile may be partial
+    Q.counts[sgm * RT_CSTRIDE] = c;
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    cnt.flush_closest(F.counters);
+    if (traced) rt_atomic_add_u64(&F.counters->rays_primary, traced);
+  }
 }
 
 // TLAS = true: the instance BVH is walked per lane (scenes with many instances) instead of the wave-uniform table loop.

@@ -1096,7 +1096,7 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if (!ctx->frame_mem.empty() && !std::memcmp(key, ctx->frame_key, sizeof key)) return RT_OK;
   free_pool(ctx->frame_mem);
   std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
-  // k_raygen deals 64-path tiles round-robin to NSEG segments; children stay in their parent's segment
+  // k_raygen_trace deals 64-path tiles round-robin to NSEG segments; children stay in their parent's segment
   size_t tiles = ((size_t)fp.budget + 63) / 64;
   size_t seg0 = ((tiles + NSEG - 1) / NSEG) * 64;
   auto cap_of = [&](double f) { return (size_t)std::min<double>(std::ceil((double)seg0 * f) + 64.0, 3.0e8 / NSEG); };
@@ -1207,9 +1207,18 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
   uint32_t n0 = P.n_pix * (uint32_t)P.n_samples;
   RayQ Qc = ctx->Q[0], Qn = ctx->Q[1];
   Qc.counts = ctx->d_counts + cnt_at(0, CNT_Q);
-  {
+  const bool meshes = ctx->n_minst > 0;
+  auto meshq = [&](const MeshQ& base, int lvl, int kind_cnt, int kind_cur) {
+    MeshQ q = base;
+    q.counts = ctx->d_counts + cnt_at(lvl, kind_cnt);
+    q.cursor = ctx->d_counts + cnt_at(lvl, kind_cur);
+    return q;
+  };
+  {  // camera rays + their first phase (instance table)
+    MeshQ MQ = meshq(ctx->MQ, 0, CNT_MQ, CUR_MQ);
     Timer t(ctx, RT_K_RAYGEN);
-    LAUNCH(k_raygen, n0, ctx->ds, P, F, Qc);
+    if (ctx->ds.use_tlas) LAUNCH_T((k_raygen_trace<CNT, true>), n0, ctx->ds, P, F, Qc, MQ);
+    else LAUNCH_P1((k_raygen_trace<CNT, false>), n0, ctx->ds, P, F, Qc, MQ);
     t.stop((1ull << 32) + n0);
   }
   double ub = n0;
@@ -1224,19 +1233,14 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     GQ.counts = ctx->d_counts + cnt_at(lvl, CNT_GQ);
     uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
-    const bool meshes = ctx->n_minst > 0;
-    auto meshq = [&](const MeshQ& base, int kind_cnt, int kind_cur) {
-      MeshQ q = base;
-      q.counts = ctx->d_counts + cnt_at(lvl, kind_cnt);
-      q.cursor = ctx->d_counts + cnt_at(lvl, kind_cur);
-      return q;
-    };
     {
-      MeshQ MQ = meshq(ctx->MQ, CNT_MQ, CUR_MQ);
-      Timer t(ctx, RT_K_TRACE_CLOSEST);
-      if (ctx->ds.use_tlas) LAUNCH_T((k_trace_closest<CNT, true>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
-      else LAUNCH_P1((k_trace_closest<CNT, false>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
-      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+      MeshQ MQ = meshq(ctx->MQ, lvl, CNT_MQ, CUR_MQ);
+      if (lvl > 0) {  // (level 0 went through k_raygen_trace)
+        Timer t(ctx, RT_K_TRACE_CLOSEST);
+        if (ctx->ds.use_tlas) LAUNCH_T((k_trace_closest<CNT, true>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+        else LAUNCH_P1((k_trace_closest<CNT, false>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+        t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+      }
       if (meshes) {
         Timer t2(ctx, RT_K_TRACE_MESH);
         LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
@@ -1250,7 +1254,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
-      MeshQ MH = meshq(ctx->MH, CNT_MH, CUR_MH);
+      MeshQ MH = meshq(ctx->MH, lvl, CNT_MH, CUR_MH);
       uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
       if (ctx->ds.use_tlas) LAUNCH_T((k_shadow_hard<CNT, true>), gh_ub, ctx->ds, P, F, GH, MH);
       else LAUNCH_P1((k_shadow_hard<CNT, false>), gh_ub, ctx->ds, P, F, GH, MH);
@@ -1263,7 +1267,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (any_soft) {
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
-      MeshQ MS1 = meshq(ctx->MS, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, CNT_MS2, CUR_MS2);
+      MeshQ MS1 = meshq(ctx->MS, lvl, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, lvl, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
       {
         Timer t(ctx, RT_K_SHADOW);
