@@ -282,6 +282,24 @@ RT_DEV bool plane_any(V3 p, V3 d, float t_max) {
   return false;
 }
 
+// wave-wide minimum / maximum (every lane of the wave must call)
+#ifndef RT_EMU
+// (the result is read back through readfirstlane so that the compiler keeps it in a scalar register)
+RT_DEV float wave_min(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+RT_DEV float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+#else
+RT_DEV float wave_min(float v) { return v; }
+RT_DEV float wave_max(float v) { return v; }
+#endif
+
 // hitAABB, objects.cpp:94-120, returning also the entry parameter.  The ternaries keep FAST_MIN/FAST_MAX's
 // behaviour for NaN operands (0 * inf when a ray lies in a slab plane).
 #define RT_FMIN(a, b) ((a) < (b) ? (a) : (b))
@@ -876,8 +894,10 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 
 // Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
 // SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
+// `active`: this lane has a ray (the first-phase kernels call with every lane of the wave, see the wave-wide cull below).
 template <bool CNT, bool SPLIT>
-RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt,
+                          bool active = true) {
   V3 winv = v3(0, 0, 0);
   if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
@@ -886,12 +906,28 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
   pr.key = -2; pr.p = o; pr.d = dir;
   bool occluded = false;
   mesh_flag = false;
+  // Box around the segments the WAVE's rays can be occluded on, [o, o + dir * t_max] (the rays of a wave are neighbours:
+  // samples of the same few shadow groups).  An instance whose padded world box does not overlap it cannot occlude any
+  // of them (an occluding point lies on a segment and inside the instance), so the whole wave skips its transform and
+  // test: six compares on wave-uniform values against the scalar-loaded box instead of ~100 instructions.  The reference
+  // tests every node for every ray (RayTracer.cpp:346-371); the result is the same.  (A per-lane skip does not pay: the
+  // wave still runs the test whenever one lane needs it.)
+  V3 smin = v3(-RT_BIG, -RT_BIG, -RT_BIG), smax = v3(RT_BIG, RT_BIG, RT_BIG);
+  if (SPLIT) {
+    const float tseg = t_max < 1e30f ? t_max : 1e30f;
+    const V3 e = o + dir * tseg;
+    smin = v3(wave_min(active ? fminf(o.x, e.x) : RT_BIG), wave_min(active ? fminf(o.y, e.y) : RT_BIG), wave_min(active ? fminf(o.z, e.z) : RT_BIG));
+    smax = v3(wave_max(active ? fmaxf(o.x, e.x) : -RT_BIG), wave_max(active ? fmaxf(o.y, e.y) : -RT_BIG), wave_max(active ? fmaxf(o.z, e.z) : -RT_BIG));
+  }
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
+    if (SPLIT && (smin.x > I->wmax[0] || smax.x < I->wmin[0] || smin.y > I->wmax[1] || smax.y < I->wmin[1] || smin.z > I->wmax[2] ||
+                  smax.z < I->wmin[2]))
+      continue;  // [wave-uniform]
     int prim = I->prim;
     V3 p, d;
     ray_to_instance(I, xf, o, dir, pr, p, d);
-    if (occluded) continue;  // lanes that already found an occluder idle; the loop itself stays wave-uniform
+    if (occluded || !active) continue;  // lanes that already found an occluder idle; the loop itself stays wave-uniform
     if (prim == 3) {
       float tm;
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;

@@ -953,22 +953,28 @@ RT_DEV void soft_shadow_ray(const DScene& S, float4 g0, float4 g2, float4 g3, fl
 }
 
 // Hard shadows: one ray per group (DirectLight, and PointLight of size 0).
+#ifndef RT_SHADOW_P1_WAVES
+#define RT_SHADOW_P1_WAVES 8   // C3 shadows: 5 -> 108.7 ms, 6 -> 105.3 ms, 8 -> 102.9 ms per step
+#endif
 template <bool CNT, bool TLAS>
-RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
+RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
   uint32_t rays = 0;
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
     bool need_mesh = false;
+    V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
+    float tmax = 0.0f;
     if (seg_valid) {
-      float4 g1 = G.g1[g];
-      V3 Pp, d;
-      float tmax;
       hard_shadow_ray(S, G.g0[g], Pp, d, tmax);
       rays++;
-      bool occ = TLAS ? any_instances_tlas<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt)
-                      : any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
+    }
+    bool occ;
+    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
+    else occ = any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull)
+    if (seg_valid) {
+      float4 g1 = G.g1[g];
       if (occ) need_mesh = false;
       else if (!need_mesh) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
     }
@@ -988,25 +994,33 @@ RT_KERNEL(k_shadow_hard, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
 // Soft shadows, phases of PointLight::Illuminate's sample loop: `j0` .. `j0 + nj - 1` of every group (`list` = null:
 // all groups of the queue; else the groups listed, i.e. those not fully lit after the first shadow_min samples).
 template <bool CNT, bool TLAS>
-RT_KERNEL(k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list, const uint32_t* list_counts, uint32_t j0,
+RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, GroupQ G, const uint32_t* list, const uint32_t* list_counts, uint32_t j0,
           uint32_t nj, MeshQ MQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
   uint32_t rays = 0;
   const uint32_t* counts = list ? list_counts : G.counts;
+  const unsigned long long nj_magic = ((1ull << 40) + nj - 1u) / nj;   // ceil(2^40 / nj): e / nj == (e * magic) >> 40 for e < 2^32
   RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
     uint32_t g = RT_NONE, j = 0;
     bool need_mesh = false, lit = false;
+    V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
+    float dist = 0.0f;
     if (seg_valid) {
-      uint32_t e = seg_base_ + (uint32_t)(seg_e / nj);
+      // group and sample of work item seg_e: a 64-bit division per ray was the largest single cost of this kernel;
+      // items per segment fit 32 bits and nj <= 128, for which the multiply-shift below is exact
+      const uint32_t e32 = (uint32_t)seg_e;
+      const uint32_t q = nj <= 128u ? (uint32_t)(((unsigned long long)e32 * nj_magic) >> 40) : e32 / nj;
+      uint32_t e = seg_base_ + q;
       g = list ? list[e] : e;
-      j = j0 + (uint32_t)(seg_e % nj);
-      V3 Pp, d;
-      float dist;
+      j = j0 + (e32 - q * nj);
       soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], G.g4[g], j, Pp, d, dist);
       rays++;
-      bool occ = TLAS ? any_instances_tlas<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt)
-                      : any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
+    }
+    bool occ;
+    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
+    else occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull)
+    if (seg_valid) {
       if (occ) need_mesh = false;
       else if (!need_mesh) lit = true;
     }
