@@ -31,10 +31,19 @@ class Config:
     """One BASELINE.json configuration.  The driver runs the default (c2, configs[1]: the largest that BASELINE quotes
     on ONE MI355X); the others are selectable with --config for the measurements recorded in BASELINE.md / DESIGN.md."""
 
-    def __init__(self, name, workload, width, height, spp_per_step, scene, tweak, cpu_tile_stride=1):
+    def __init__(self, name, workload, width, height, spp_per_step, scene, tweak, cpu_tile_stride=1, progressive_spp=0):
         self.name, self.workload, self.width, self.height = name, workload, width, height
         self.spp_per_step, self.scene_fn, self.tweak = spp_per_step, scene, tweak
         self.cpu_tile_stride = cpu_tile_stride   # the CPU baseline renders every n-th 32x32 tile (bounded sample)
+        # > 0: consecutive steps render consecutive sample ranges of a frame of this many spp, as the passes of a
+        # progressive render do (C4: the renderer keeps per-pixel photon-lookup hints between passes, so repeating ONE
+        # range would hand every lookup its own previous answer)
+        self.progressive_spp = progressive_spp
+
+    def sample_begin(self, step, rank, world):
+        if self.progressive_spp <= 0:
+            return rank * self.spp_per_step
+        return ((step * world + rank) * self.spp_per_step) % self.progressive_spp
 
     def scene(self):
         return self.scene_fn()
@@ -124,7 +133,8 @@ CONFIGS = {
                  "indirect diffuse 2 bounces + 3 specular bounces, soft shadows 16..128 rays; 8 of the 1024 spp per step", 3840, 2160, 8,
                  _load("scenes/c3_cornell_textured.xml"), _c3, cpu_tile_stride=16),
     "c4": Config("c4", "C4: Cornell box (tests/golden/scenes/cornell_box.xml), 2 x 100k photons rebuilt every step, k=128 r=3 gather, "
-                 "soft shadows, 3 bounces", 1920, 1080, 8, _load("tests/golden/scenes/cornell_box.xml"), _c4, cpu_tile_stride=8),
+                 "soft shadows, 3 bounces; step i renders samples [8i, 8i+8) of a 128-spp frame", 1920, 1080, 8,
+                 _load("tests/golden/scenes/cornell_box.xml"), _c4, cpu_tile_stride=8, progressive_spp=128),
     "spheres": Config("spheres", "scene-graph stress (stand-in for the reference's scenes/volumetric_spiral.xml): 2944 glass spheres under "
                       "one group node + floor sphere, point light of size 0, 3 bounces reflection + refraction", 1920, 1080, 4, _sphere_field,
                       lambda p: None, cpu_tile_stride=16),
@@ -216,6 +226,7 @@ def main():
         frame[0] += 1
         if pending[k] is not None:
             pending[k].wait()
+        p.sample_begin = cfg.sample_begin(frame[0] - 1, rank, world)
         accum = accums[k]
         accum.zero_()
         torch.cuda.synchronize()

@@ -188,15 +188,20 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 // distance decides the exception.  Per-lane memory is the kd walk stack only.  The photon SET is the reference's (equal
 // d' values among different photons are resolved by visiting order here and by heap history there); the power sum runs
 // in visiting order instead of heap order, i.e. irradiance agrees to float-sum reordering (tests: 2e-5 relative).
-struct HeapMem {     // per-lane views of the kd walk stack: entry i of this lane is at [i * stride]
-  uint32_t* walk;    // node index << 2 | state
-  float* wdist;      // signed distance of the query to that node's splitting plane
+struct HeapMem {     // per-lane views of the lookup's LDS: entry i of this lane is at [i * stride]
+  uint32_t* walk;    // kd walk stack: node index << 4 | split axis << 2 | state (pre-order walks: the node index alone)
+  uint32_t* list;    // RT_SEL entries: the collecting walk's bracket photons in visiting order
   uint32_t stride;
 };
 
 RT_DEV V3 photon_power(float4 pa, float4 pb) {  // PhotonData::GetPower = Color24::ToColor() * power
   uint32_t bits = __float_as_uint(pb.w);
   return v3((float)(bits & 255u) / 255.0f, (float)((bits >> 8) & 255u) / 255.0f, (float)((bits >> 16) & 255u) / 255.0f) * pa.w;
+}
+
+RT_DEV V3 photon_power_raw(float4 pa, float4 pb) {  // 255 x GetPower: the division is applied once to a sum of these
+  uint32_t bits = __float_as_uint(pb.w);
+  return v3((float)(bits & 255u), (float)((bits >> 8) & 255u), (float)((bits >> 16) & 255u)) * pa.w;
 }
 
 // Visits, in LocatePhotons' order, every photon of the kd-tree that is eligible under the FIXED squared radius `bound`
@@ -217,8 +222,7 @@ RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
         float pc = axis == 0 ? pa.x : (axis == 1 ? pa.y : pa.z);
         float qc = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
         float dist = qc - pc;
-        hm.walk[sp * hs] = (index << 2) | 1u;
-        hm.wdist[sp * hs] = dist;
+        hm.walk[sp * hs] = (index << 4) | ((uint32_t)axis << 2) | 1u;
         sp++;
         index = dist > 0.0f ? 2 * index + 1 : 2 * index;
         continue;
@@ -242,11 +246,15 @@ RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
     for (;;) {  // back up: second child if the splitting plane is within the radius, then the node's own photon
       if (sp == 0) return;
       uint32_t w = hm.walk[(sp - 1) * hs];
-      index = w >> 2;
+      index = w >> 4;
       if ((w & 3u) == 1u) {
-        float dist = hm.wdist[(sp - 1) * hs];
+        // the signed distance to the node's splitting plane, recomputed from the node's photon as on the way down
+        int axis = (int)((w >> 2) & 3u);
+        float pc = ((const float*)M.ph)[8 * (size_t)index + axis];
+        float qc = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
+        float dist = qc - pc;
         if (dist * dist < bound) {
-          hm.walk[(sp - 1) * hs] = (index << 2) | 2u;
+          hm.walk[(sp - 1) * hs] = (w & ~3u) | 2u;
           index = dist > 0.0f ? 2 * index : 2 * index + 1;
           enter = true;
           break;
@@ -257,6 +265,24 @@ RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
       break;
     }
   }
+}
+
+// Eligibility of one photon for a query under the squared radius `bound` (photonmap.h:357-373); d2 is its (ellipsoidal)
+// squared distance.  One definition, so that a distance recomputed later is the same float.
+RT_DEV bool photon_eligible(float4 pa, float4 pb, V3 pos, V3 normal, float normScale, float bound, float& d2) {
+  V3 dif = v3(pa.x, pa.y, pa.z) - pos;
+  float dist2 = dot(dif, dif);
+  if (!(dist2 < bound)) return false;
+  V3 dir = v3(pb.x, pb.y, pb.z);
+  if (dot(dir, normal) >= 0.0f) return false;
+  if (normScale > 0.0f) {
+    float perp = dot(dif, normal);
+    dif = dif + normal * (perp * normScale);
+    dist2 = dot(dif, dif);
+    if (dist2 >= bound) return false;
+  }
+  d2 = dist2;
+  return true;
 }
 
 // The same set of photons in pre-order (node, nearer child, farther child): with a FIXED radius the decision to enter
@@ -281,19 +307,8 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
       next = dist > 0.0f ? 2 * index + 1 : 2 * index;
       if (dist * dist < bound) hm.walk[(sp++) * hs] = next ^ 1u;  // the sibling
     }
-    V3 dif = v3(pa.x, pa.y, pa.z) - pos;
-    float dist2 = dot(dif, dif);
-    if (dist2 < bound) {
-      V3 dir = v3(pb.x, pb.y, pb.z);
-      bool keep = !(dot(dir, normal) >= 0.0f);
-      if (keep && normScale > 0.0f) {
-        float perp = dot(dif, normal);
-        dif = dif + normal * (perp * normScale);
-        dist2 = dot(dif, dif);
-        if (dist2 >= bound) keep = false;
-      }
-      if (keep) f(dist2, index, pa, pb);
-    }
+    float dist2;
+    if (photon_eligible(pa, pb, pos, normal, normScale, bound, dist2)) f(dist2, index, pa, pb);
     if (next == 0) {
       if (sp == 0) return;
       next = hm.walk[(--sp) * hs];
@@ -306,12 +321,127 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
 #define RT_TEST_NO_EVICT_RULE 0   // tests build a variant with 1 to prove that the exception below is exercised
 #endif
 #define RT_SEL 16   // thresholds per counting walk = photons kept sorted by the collecting walk
-// `guess`: in, a squared radius expected to hold about k + 1 eligible photons (<= 0: none yet); out, what this query
-// needed.  Only the number of walks depends on it, never the result.
+
+// What the collecting walk over the bracket [lo, hi) leaves behind.
+struct Collected {
+  float ed[RT_SEL];      // the bracket's photons sorted by d' (ties in visiting order): the RT_SEL smallest
+  uint32_t ei[RT_SEL];
+  V3 raw;                // sum of (8-bit colour) x power below the bracket; Color24::ToColor's / 255 is applied to the sum
+  uint32_t n_below, n_all;
+  float max_d;           // largest d' among the photons below the bracket, and which photon that is
+  uint32_t max_i;
+};
+
+RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float lo, float hi, const HeapMem& hm, uint32_t& visits,
+                           Collected& C) {
+#pragma unroll
+  for (int i = 0; i < RT_SEL; i++) { C.ed[i] = RT_BIG; C.ei[i] = 0; }
+  C.raw = v3(0, 0, 0);
+  C.n_below = 0; C.n_all = 0;
+  C.max_d = -1.0f; C.max_i = 0;
+  auto insert_sorted = [&](float nd, uint32_t ni) {
+#pragma unroll
+    for (int i = 0; i < RT_SEL; i++) {
+      bool sw = nd < C.ed[i];
+      float td = C.ed[i]; uint32_t ti = C.ei[i];
+      C.ed[i] = sw ? nd : td; C.ei[i] = sw ? ni : ti;
+      nd = sw ? td : nd; ni = sw ? ti : ni;
+    }
+  };
+  // The walk only notes which photons fall into the bracket (their indices, in visiting order, in the lane's LDS list):
+  // sorting them inside the walk would issue the whole insertion network whenever ANY lane of the wave meets one.  They
+  // are fetched again and sorted after the walk, all lanes together.  A bracket of more than RT_SEL photons (thresholds
+  // that cannot separate equal d' values) keeps its RT_SEL smallest by sorting inside the walk, as before.
+  uint32_t n_list = 0;
+  bool spilled = false;
+  const uint32_t hs = hm.stride;
+  photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t index, float4 pa, float4 pb) {
+    C.n_all++;
+    if (d2 < lo) {
+      C.n_below++;
+      C.raw = C.raw + photon_power_raw(pa, pb);
+      if (d2 > C.max_d) { C.max_d = d2; C.max_i = index; }
+      return;
+    }
+    if (n_list < RT_SEL) { hm.list[(n_list++) * hs] = index; return; }
+    if (!spilled) {   // the list is full: sort what it holds, then carry on sorting in place
+      spilled = true;
+      for (uint32_t i = 0; i < RT_SEL; i++) {
+        uint32_t pi = hm.list[i * hs];
+        float4 qa = M.ph[2 * (size_t)pi], qb = M.ph[2 * (size_t)pi + 1];
+        float qd = 0.0f;
+        (void)photon_eligible(qa, qb, pos, normal, normScale, hi, qd);
+        insert_sorted(qd, pi);
+      }
+    }
+    insert_sorted(d2, index);
+  });
+  if (!spilled) {
+    for (uint32_t i = 0; i < RT_SEL; i++) {
+      if (i >= n_list) break;
+      uint32_t pi = hm.list[i * hs];
+      float4 qa = M.ph[2 * (size_t)pi], qb = M.ph[2 * (size_t)pi + 1];
+      float qd = 0.0f;
+      (void)photon_eligible(qa, qb, pos, normal, normScale, hi, qd);
+      insert_sorted(qd, pi);
+    }
+  }
+}
+
+// The estimate from a collected bracket with C(lo) <= k < C(hi) (or, `all`, from everything within the radius).
+// `hint` out: the (k+1)-th smallest d' (radius^2 when at most k photons are in range).
+RT_DEV V3 photon_finish(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float r2, uint32_t K, bool all, const HeapMem& hm,
+                        uint32_t& visits, const Collected& C, float& guess, float& hint) {
+  if (C.n_all == 0) { hint = r2; return v3(0, 0, 0); }
+  V3 sum = C.raw / 255.0f;
+  float bound, next_hint;
+  if (all) {  // |U| <= k: everything was summed (lo = radius^2), area from the search radius (dist2[0] never changes)
+    bound = r2;
+    next_hint = r2;
+  } else {
+    // ranks n_below + 1 .. in the bracket list; rank k is the last one kept, rank k + 1 decides the exception
+    const uint32_t j_k = K - 1 - C.n_below, j_k1 = K - C.n_below;  // list positions of the k-th and (k+1)-th nearest
+    float d_k = C.max_d, d_k1 = RT_BIG;
+    uint32_t i_k = C.max_i, i_k1 = 0;
+    bool have_k1 = false;
+#pragma unroll
+    for (int i = 0; i < RT_SEL; i++) {
+      if ((uint32_t)i <= j_k && C.n_below < K && C.ed[i] < RT_BIG) {
+        sum = sum + photon_power(M.ph[2 * (size_t)C.ei[i]], M.ph[2 * (size_t)C.ei[i] + 1]);
+        if ((uint32_t)i == j_k) { d_k = C.ed[i]; i_k = C.ei[i]; }
+      }
+      if ((uint32_t)i == j_k1 && C.ed[i] < RT_BIG) { d_k1 = C.ed[i]; i_k1 = C.ei[i]; have_k1 = true; }
+    }
+    bound = d_k;
+    next_hint = have_k1 ? d_k1 : d_k;
+    if (have_k1) {
+      // the exception: the first k eligible photons in visiting order are the k nearest (none beyond the k-th distance)
+      uint32_t seen = 0;
+      bool beyond = false;
+      photon_walk(M, pos, normal, normScale, r2, hm, visits, [&](float d2, uint32_t, float4, float4) {
+        if (d2 > d_k) { beyond = true; return true; }
+        return ++seen == K;
+      });
+      if (!beyond && seen == K && !RT_TEST_NO_EVICT_RULE) {
+        sum = sum - photon_power(M.ph[2 * (size_t)i_k], M.ph[2 * (size_t)i_k + 1]);
+        sum = sum + photon_power(M.ph[2 * (size_t)i_k1], M.ph[2 * (size_t)i_k1 + 1]);
+        bound = d_k1;
+      }
+    }
+  }
+  guess = all ? r2 : bound * 1.25f;
+  hint = next_hint;
+  float area = RT_PI_F * bound;
+  if (area > 0.0f) sum = sum * (1.0f / area);
+  return sum;
+}
+
+// The lookup from scratch.  `guess`: in, a squared radius expected to hold about k + 1 eligible photons (<= 0: none
+// yet); out, what this query needed.  Only the number of walks depends on it, never the result.  `hint`: out, see
+// photon_finish.
 RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, float ellipticity, int k, const HeapMem& hm,
-                          uint32_t& visits, float& guess) {
-  V3 irrad = v3(0, 0, 0);
-  if (M.stored == 0) return irrad;
+                          uint32_t& visits, float& guess, float& hint) {
+  if (M.stored == 0) { hint = 0.0f; return v3(0, 0, 0); }
   const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
@@ -358,89 +488,65 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
     lo = nlo; hi = nhi; c_lo = nclo; c_hi = nchi;
   }
   // ---- collect: powers below the bracket, the bracket's photons sorted by d' (ties in visiting order)
-  float ed[RT_SEL];
-  uint32_t ei[RT_SEL];
-#pragma unroll
-  for (int i = 0; i < RT_SEL; i++) { ed[i] = RT_BIG; ei[i] = 0; }
-  V3 sum = v3(0, 0, 0);
-  uint32_t n_below = 0, n_all = 0;
-  float max_d = -1.0f;       // largest d' among the photons summed so far, and which photon that is
-  uint32_t max_i = 0;
-  photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t index, float4 pa, float4 pb) {
-    n_all++;
-    if (d2 < lo) {
-      n_below++;
-      sum = sum + photon_power(pa, pb);
-      if (d2 > max_d) { max_d = d2; max_i = index; }
-      return;
-    }
-    float nd = d2;
-    uint32_t ni = index;
-#pragma unroll
-    for (int i = 0; i < RT_SEL; i++) {
-      bool sw = nd < ed[i];
-      float td = ed[i]; uint32_t ti = ei[i];
-      ed[i] = sw ? nd : td; ei[i] = sw ? ni : ti;
-      nd = sw ? td : nd; ni = sw ? ti : ni;
-    }
-  });
-  if (n_all == 0) return irrad;
-  float bound;
-  if (all) {  // |U| <= k: everything was summed (lo = radius^2), area from the search radius (dist2[0] never changes)
-    bound = r2;
+  Collected C;
+  photon_collect(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  return photon_finish(M, pos, normal, normScale, r2, K, all, hm, visits, C, guess, hint);
+}
+
+// The lookup from a hint: the (k+1)-th smallest d' that a lookup at (nearly) the same place found before (>= radius^2:
+// it found at most k photons within the radius).  The collecting walk runs at once, on a narrow bracket around the
+// hint, and the bracket is checked afterwards against what the counting walks would have established.  true: E is the
+// estimate (the same photon set as photon_estimate's) at the price of one fixed-radius walk and the short walk of the
+// exception test.  false: the bracket missed; `hint` then holds MINUS a squared radius to start the counting walks
+// from.  Most lookups of a frame's later passes — and, within a pass, of a pixel's later samples — succeed.
+RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float radius, float ellipticity, int k, const HeapMem& hm,
+                                   uint32_t& visits, float& hint, V3& E) {
+  if (M.stored == 0) { E = v3(0, 0, 0); return true; }
+  const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
+  const float r2 = radius * radius;
+  const uint32_t K = (uint32_t)k;
+  const float delta = fminf(0.25f, 5.0f / (float)(K + 1));   // about 10 photons in the bracket
+  float lo, hi;
+  if (hint * (1.0f + delta) >= r2) {
+    lo = hi = r2;        // expect at most k photons within the radius (the bracket may not reach beyond it)
   } else {
-    // ranks n_below + 1 .. in the bracket list; rank k is the last one kept, rank k + 1 decides the exception
-    const uint32_t j_k = K - 1 - n_below, j_k1 = K - n_below;  // list positions of the k-th and (k+1)-th nearest
-    float d_k = max_d, d_k1 = RT_BIG;
-    uint32_t i_k = max_i, i_k1 = 0;
-    bool have_k1 = false;
-#pragma unroll
-    for (int i = 0; i < RT_SEL; i++) {
-      if ((uint32_t)i <= j_k && n_below < K && ed[i] < RT_BIG) {
-        sum = sum + photon_power(M.ph[2 * (size_t)ei[i]], M.ph[2 * (size_t)ei[i] + 1]);
-        if ((uint32_t)i == j_k) { d_k = ed[i]; i_k = ei[i]; }
-      }
-      if ((uint32_t)i == j_k1 && ed[i] < RT_BIG) { d_k1 = ed[i]; i_k1 = ei[i]; have_k1 = true; }
-    }
-    bound = d_k;
-    if (have_k1) {
-      // the exception: the first k eligible photons in visiting order are the k nearest (none beyond the k-th distance)
-      uint32_t seen = 0;
-      bool beyond = false;
-      photon_walk(M, pos, normal, normScale, r2, hm, visits, [&](float d2, uint32_t, float4, float4) {
-        if (d2 > d_k) { beyond = true; return true; }
-        return ++seen == K;
-      });
-      if (!beyond && seen == K && !RT_TEST_NO_EVICT_RULE) {
-        sum = sum - photon_power(M.ph[2 * (size_t)i_k], M.ph[2 * (size_t)i_k + 1]);
-        sum = sum + photon_power(M.ph[2 * (size_t)i_k1], M.ph[2 * (size_t)i_k1 + 1]);
-        bound = d_k1;
-      }
-    }
+    lo = hint * (1.0f - delta);
+    hi = hint * (1.0f + delta);
   }
-  guess = all ? r2 : bound * 1.25f;
-  float area = RT_PI_F * bound;
-  if (area > 0.0f) sum = sum * (1.0f / area);
-  return sum;
+  Collected C;
+  photon_collect(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  bool all = false;
+  if (hi == r2) {
+    if (C.n_all > K) { hint = -0.5f * r2; return false; }
+    all = true;
+  } else if (!(C.n_below <= K && C.n_all >= K + 1 && C.n_all - C.n_below <= RT_SEL)) {
+    // what this walk saw seeds the counting walks: the answer lies below hi, or above it
+    float grow = C.n_all >= 8 ? 1.3f * (float)(K + 1) / (float)C.n_all : 4.0f;
+    hint = -(C.n_all >= K + 1 ? hi : fminf(hi * (grow > 1.25f ? grow : 1.25f), 0.999f * r2));
+    return false;
+  }
+  float guess_unused;
+  E = photon_finish(M, pos, normal, normScale, r2, K, all, hm, visits, C, guess_unused, hint);
+  return true;
 }
 
 #ifndef RT_EMU
 #define RT_GATHER_BLOCK 64
-// dynamic LDS: walk[depth][64], wdist[depth][64]
+// dynamic LDS: walk[depth][64], list[RT_SEL][64]
 #define RT_HEAP_DECL(depth_)                                                               \
   extern __shared__ uint32_t s_heap_raw[];                                                 \
   HeapMem hm;                                                                              \
   hm.stride = RT_GATHER_BLOCK;                                                             \
   hm.walk = s_heap_raw + threadIdx.x;                                                      \
-  hm.wdist = (float*)s_heap_raw + (size_t)(depth_) * RT_GATHER_BLOCK + threadIdx.x;
-static inline size_t photon_heap_bytes(int depth) { return (size_t)2 * depth * RT_GATHER_BLOCK * 4; }
+  hm.list = s_heap_raw + (size_t)(depth_) * RT_GATHER_BLOCK + threadIdx.x;
+static inline size_t photon_heap_bytes(int depth) { return (size_t)(depth + RT_SEL) * RT_GATHER_BLOCK * 4; }
 #else
 #define RT_GATHER_BLOCK 1
 #define RT_HEAP_DECL(depth_)                                                               \
   static uint32_t e_walk[RT_PHOTON_TSTACK];                                                \
-  static float e_wdist[RT_PHOTON_TSTACK];                                                  \
+  static uint32_t e_list[RT_SEL];                                                          \
   HeapMem hm;                                                                              \
-  hm.stride = 1; hm.walk = e_walk; hm.wdist = e_wdist;
+  hm.stride = 1; hm.walk = e_walk; hm.list = e_list;
 static inline size_t photon_heap_bytes(int) { return 0; }
 #endif
 // levels of a heap-ordered kd-tree over n photons (+1 spare): the walk stack holds one entry per level
@@ -456,28 +562,65 @@ struct GatherP {
   float ellipticity[2];
   int32_t k;
   int32_t depth;   // walk stack entries per lane
+  uint32_t n_pix;  // pixels of the pass (path slot -> pixel)
+  float* hints;    // [W * H][2]: per pixel and map, the (k+1)-th smallest d' of the last lookup (0: none; < 0: minus a
+                   // starting radius for the second stage); null without hints (STAGE 0)
+  uint32_t* retry;          // STAGE 1 -> 2: queue entries still to do, segmented like the queue itself
+  uint32_t* retry_counts;
 };
 
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
 #endif
-template <bool CNT>
+// STAGE 0: every lookup from scratch (no hint buffer).  With hints the queue is taken in two stages, because a wave is
+// as slow as its slowest lane: STAGE 1 tries every hinted lookup (one walk + the exception test) and lists the ones
+// without a hint or whose bracket missed; STAGE 2 runs the listed lookups from scratch, packed densely into waves.
+template <bool CNT, int STAGE>
 RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
   RT_HEAP_DECL(G.depth)
   uint32_t visits = 0, gathers = 0;
   float guess[2] = {0.0f, 0.0f};  // per map: the squared radius the lane's previous lookup needed
-  RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
-    if (!seg_valid) continue;
+  RT_SEG_BEGIN((STAGE == 2 ? G.retry_counts : Q.counts), Q.nseg, Q.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
-    float4 a = Q.a[g], b = Q.b[g], c = Q.c[g];
-    uint32_t which = __float_as_uint(b.w) & 1u;
-    const DPhotonMap& M = which ? G.map[1] : G.map[0];
-    if (M.stored > 0) gathers++;
-    float gs = which ? guess[1] : guess[0];
-    V3 E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, which ? G.ellipticity[1] : G.ellipticity[0], G.k, hm, visits, gs);
-    if (which) guess[1] = gs; else guess[0] = gs;
-    add_radiance(F, __float_as_uint(a.w), v3(c.x, c.y, c.z) * E);
+    if (STAGE == 2 && seg_valid) g = G.retry[g];
+    bool todo = seg_valid;   // (every lane reaches the append below)
+    if (seg_valid) {
+      float4 a = Q.a[g], b = Q.b[g], c = Q.c[g];
+      uint32_t which = __float_as_uint(b.w) & 1u;
+      const DPhotonMap& M = which ? G.map[1] : G.map[0];
+      const float ell = which ? G.ellipticity[1] : G.ellipticity[0];
+      // what the last lookup of this pixel into this map found (an earlier pass of the frame, or another sample of the
+      // pixel in this pass): a plain load and store, any value is only a hint
+      float* hp = STAGE == 0 ? nullptr : G.hints + 2 * (size_t)F.pixels[__float_as_uint(a.w) % G.n_pix] + which;
+      V3 E = v3(0, 0, 0);
+      if (STAGE == 1) {
+        float hint = *hp;
+        if (hint > 0.0f) {
+          todo = !photon_estimate_hinted(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, hint, E);
+          *hp = hint;
+        }
+      } else {
+        float gs = which ? guess[1] : guess[0];
+        if (STAGE == 2) {
+          float seed = *hp;
+          if (seed < 0.0f) gs = -seed;
+        }
+        float hint;
+        E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, gs, hint);
+        if (STAGE == 2) *hp = hint;
+        if (which) guess[1] = gs; else guess[0] = gs;
+        todo = false;
+      }
+      if (!todo) {
+        if (M.stored > 0) gathers++;
+        add_radiance(F, __float_as_uint(a.w), v3(c.x, c.y, c.z) * E);
+      }
+    }
+    if (STAGE == 1) {
+      uint32_t ri = seg_push(todo, G.retry_counts, sw_.s, Q.segcap, F.overflow);
+      if (ri != RT_NONE) G.retry[ri] = g;
+    }
   RT_SEG_END
   if (CNT) {
     if (visits) rt_atomic_add_u64(&F.counters->photon_visits, visits);
@@ -492,8 +635,9 @@ RT_KERNEL(k_api_photon_gather, DPhotonMap M, const float* P, const float* N, uin
   uint32_t visits = 0;
   float guess = 0.0f;
   for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) {
+    float hint = 0.0f;
     V3 E = photon_estimate(M, v3(P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2]),
-                           v3(N[3 * (size_t)i], N[3 * (size_t)i + 1], N[3 * (size_t)i + 2]), radius, ellipticity, k, hm, visits, guess);
+                           v3(N[3 * (size_t)i], N[3 * (size_t)i + 1], N[3 * (size_t)i + 2]), radius, ellipticity, k, hm, visits, guess, hint);
     out[3 * (size_t)i] = E.x; out[3 * (size_t)i + 1] = E.y; out[3 * (size_t)i + 2] = E.z;
   }
 }

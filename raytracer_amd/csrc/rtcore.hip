@@ -105,6 +105,7 @@ struct rt_context {
   GatherQ GQ;
   MeshQ MQ, MH, MS;
   uint32_t* d_list2 = nullptr;
+  uint32_t* d_gather_retry = nullptr;   // GatherP::retry
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
   float4* d_path_rad = nullptr;
   uint32_t* d_pixels = nullptr;
@@ -123,6 +124,8 @@ struct rt_context {
 
   // photon maps
   PhotonState photons;
+  float* d_gather_hints = nullptr;   // [W * H][2], see GatherP::hints; lives as long as the frame size
+  size_t gather_hint_px = 0;
 
   bool counters_on = false, profile_on = false;
   uint64_t host_paths = 0;
@@ -400,6 +403,7 @@ void rt_context_destroy(rt_context* ctx) {
   free_pool(ctx->scene_mem);
   free_pool(ctx->frame_mem);
   photon_state_free(ctx->photons);
+  if (ctx->d_gather_hints) (void)hipFree(ctx->d_gather_hints);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -419,6 +423,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   ctx->has_scene = false;
   ctx->fan_valid = false;
   photon_state_free(ctx->photons);
+  if (ctx->d_gather_hints) HIP_TRY(hipMemsetAsync(ctx->d_gather_hints, 0, ctx->gather_hint_px * 2 * sizeof(float), ctx->stream));
 
   // ---- nodes and instances
   for (uint32_t i = 0; i < sc->n_nodes; i++) {
@@ -698,7 +703,8 @@ namespace {
 enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4,
        CNT_MQ = 5, CNT_MH = 6, CNT_MS1 = 7, CNT_MS2 = 8,        // mesh-phase item queues: closest, hard shadow, soft shadow phases
        CUR_MQ = 9, CUR_MH = 10, CUR_MS1 = 11, CUR_MS2 = 12,     // their claim cursors
-       CNT_KINDS = 13 };
+       CNT_GR = 13,                                             // photon lookups left to the second gather stage
+       CNT_KINDS = 14 };
 constexpr int MAX_LEVELS = 8;
 constexpr uint32_t NSEG = 64;
 constexpr size_t CNT_SLAB = (size_t)NSEG * RT_CSTRIDE;                       // words per (level, kind)
@@ -1004,6 +1010,7 @@ int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out,
 
 int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* photons, int32_t n) {
   if (which < 0 || which > 1 || n < 0 || (n && !photons)) return fail(ctx, RT_ERR_INVALID, "bad photon array");
+  if (n > (1 << 26)) return fail(ctx, RT_ERR_INVALID, "more than 2^26 photons");  // the walk stack packs index << 4 | axis | state
   std::vector<rt_photon> raw(photons, photons + n);
   int rc = photon_upload_map(ps, ctx, which, raw);
   if (rc) return rc;
@@ -1061,9 +1068,28 @@ int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* 
   return RT_OK;
 }
 
+// Per-pixel lookup hints (GatherP::hints): allocated with the frame size, cleared when a scene is committed.  They stay
+// across passes and photon rebuilds — a stale hint costs one walk, never a different result.
+void ensure_gather_hints(rt_context* ctx, size_t npx) {
+  if (ctx->d_gather_hints && ctx->gather_hint_px == npx) return;
+  if (ctx->d_gather_hints) (void)hipFree(ctx->d_gather_hints);
+  ctx->d_gather_hints = nullptr;
+  ctx->gather_hint_px = 0;
+  void* p = nullptr;
+  if (hipMalloc(&p, npx * 2 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return; }  // lookups run without hints
+  if (hipMemsetAsync(p, 0, npx * 2 * sizeof(float), ctx->stream) != hipSuccess) { (void)hipFree(p); return; }
+  ctx->d_gather_hints = (float*)p;
+  ctx->gather_hint_px = npx;
+}
+
 template <bool CNT>
-void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F, const rt_render_params& RP, uint64_t upper) {
+void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F, const PassP& P, const rt_render_params& RP, uint64_t upper,
+                         uint32_t* retry_counts) {
   GatherP G;
+  G.n_pix = P.n_pix;
+  ensure_gather_hints(ctx, (size_t)P.W * (size_t)P.H);
+  G.hints = ctx->d_gather_hints;
+  if (const char* e = std::getenv("RT_GATHER_HINTS")) if (std::atoi(e) == 0) G.hints = nullptr;  // developer knob (tests run both)
   G.map[0] = photon_dmap(ctx->photons, 0);
   G.map[1] = photon_dmap(ctx->photons, 1);
   G.radius = RP.photon_radius;
@@ -1071,7 +1097,14 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.ellipticity[1] = RP.ellipticity_caustic;
   G.k = RP.photon_k;
   G.depth = photon_tree_depth(std::max(ctx->photons.count[0], ctx->photons.count[1]));
-  LAUNCH_GATHER(k_photon_gather<CNT>, upper, G.depth, G, F, GQ);
+  G.retry = ctx->d_gather_retry;
+  G.retry_counts = retry_counts;
+  if (G.hints) {
+    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
+    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+  } else {
+    LAUNCH_GATHER((k_photon_gather<CNT, 0>), upper, G.depth, G, F, GQ);
+  }
 }
 
 // Queue capacities are entries per camera sample of a pass, by kind: f[0] ray queue (levels >= 1), f[1] hard-shadow
@@ -1150,6 +1183,7 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
   ctx->GQ.counts = nullptr;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_retry = (uint32_t*)p;
   auto alloc_meshq = [&](MeshQ& q, double f, size_t item_bytes) {
     size_t sc = (fp.meshes && f > 0) ? cap_of(f) : 1;
     q.segcap = (uint32_t)sc;
@@ -1307,7 +1341,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     if (photons) {
       Timer t(ctx, RT_K_PHOTON_GATHER);
-      photon_gather_queue<CNT>(ctx, GQ, F, RP, ubn);
+      photon_gather_queue<CNT>(ctx, GQ, F, P, RP, ubn, ctx->d_counts + cnt_at(lvl, CNT_GR));
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GQ));
     }
     std::swap(Qc, Qn);

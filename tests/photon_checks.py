@@ -142,3 +142,46 @@ def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=45
     assert psnr8(g.img, c.img) >= psnr_min
     assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean() <= tol
     return g, c
+
+
+def check_gather_hints(r, scene, n_photons=3000, w=64, h=36, spp=2, tol=2e-6):
+    """The per-pixel lookup hints (GatherP::hints, rt_photon.h) may only change how many kd-tree walks a lookup takes:
+    a frame rendered with cold hints, the same frame again with the hints it left behind, a frame of other camera
+    samples started from those hints, and the same frames with the hints switched off must agree (to the order of the
+    float sums), and the warm frame must visit fewer photons."""
+    import copy
+    import os
+    r.LoadScene(scene)   # a commit clears the hints
+    p = photon_params(n_photons, w=w, h=h, spp=spp)
+    p.spp_min = p.spp_max = 2 * spp   # fixed sample count; each render takes one half of it
+    p.sample_begin, p.sample_count = 0, spp
+    p2 = copy.copy(p)
+    p2.sample_begin = spp
+
+    def same(a, b, what):   # the lookups return the same photons; where the bracket lies changes the order of the power sum
+        d = np.abs(a.radiance[..., :3] - b.radiance[..., :3])
+        assert (d <= tol * np.maximum(np.abs(b.radiance[..., :3]), 1.0)).all(), f"{what}: {d.max()}"
+        assert (a.img == b.img).mean() > 0.999, what
+
+    def render(q):
+        r.counters(enable=True, reset=True)
+        img = r.Render(q)
+        n = r.counters()["photon_visits"]
+        r.counters(enable=False)
+        return img, n
+
+    cold, n_cold = render(p)
+    warm, n_warm = render(p)
+    other, _ = render(p2)
+    os.environ["RT_GATHER_HINTS"] = "0"
+    try:
+        off, n_off = render(p)
+        other_off, _ = render(p2)
+    finally:
+        del os.environ["RT_GATHER_HINTS"]
+    assert n_cold > 0
+    same(warm, cold, "warm hints changed the frame")
+    same(off, cold, "hints changed the frame")
+    same(other_off, other, "hints from other samples changed the frame")
+    assert n_warm < 0.8 * n_off, f"warm hints save no walks: {n_warm} vs {n_off} photon visits"
+    return n_cold, n_warm, n_off

@@ -45,3 +45,7 @@ def test_no_specular_path_scene_terminates(emu):
 
 def test_photon_render(emu):
     pc.check_photon_render(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=2000, w=48, h=27, spp=2, tol=1e-4)
+
+
+def test_gather_hints_change_walks_only(emu):
+    pc.check_gather_hints(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=4000, w=48, h=27, spp=2)

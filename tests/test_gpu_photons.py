@@ -36,3 +36,7 @@ def test_photon_maps_reference_size(gpu_renderer):
 def test_photon_render(gpu_renderer):
     pc.check_photon_render(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000, w=240, h=135, spp=4,
                            psnr_min=40.0)
+
+
+def test_gather_hints_change_walks_only(gpu_renderer):
+    pc.check_gather_hints(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000, w=240, h=135, spp=4, tol=1e-5)
