@@ -563,9 +563,10 @@ struct GatherP {
   int32_t k;
   int32_t depth;   // walk stack entries per lane
   uint32_t n_pix;  // pixels of the pass (path slot -> pixel)
-  float* hints;    // [W * H][2]: per pixel and map, the (k+1)-th smallest d' of the last lookup (0: none; < 0: minus a
-                   // starting radius for the second stage); null without hints (STAGE 0)
+  float* hints;    // [W * H][2]: per pixel and map, the (k+1)-th smallest d' of the last lookup (0: none); null without
+                   // hints (STAGE 0)
   uint32_t* retry;          // STAGE 1 -> 2: queue entries still to do, segmented like the queue itself
+  float* retry_seed;        // ... and, for a lookup whose hinted bracket missed, where to start from (0: nothing known)
   uint32_t* retry_counts;
 };
 
@@ -585,6 +586,7 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
     if (STAGE == 2 && seg_valid) g = G.retry[g];
     bool todo = seg_valid;   // (every lane reaches the append below)
+    float seed = 0.0f;       // STAGE 1 -> 2: a squared radius to start the counting walks from
     if (seg_valid) {
       float4 a = Q.a[g], b = Q.b[g], c = Q.c[g];
       uint32_t which = __float_as_uint(b.w) & 1u;
@@ -598,13 +600,14 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
         float hint = *hp;
         if (hint > 0.0f) {
           todo = !photon_estimate_hinted(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, hint, E);
-          *hp = hint;
+          if (todo) seed = -hint;   // (the pixel's hint stays as it is for the other samples)
+          else *hp = hint;
         }
       } else {
         float gs = which ? guess[1] : guess[0];
         if (STAGE == 2) {
-          float seed = *hp;
-          if (seed < 0.0f) gs = -seed;
+          float sd = G.retry_seed[seg_base_ + (uint32_t)seg_e];
+          if (sd > 0.0f) gs = sd;
         }
         float hint;
         E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, gs, hint);
@@ -619,7 +622,7 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
     }
     if (STAGE == 1) {
       uint32_t ri = seg_push(todo, G.retry_counts, sw_.s, Q.segcap, F.overflow);
-      if (ri != RT_NONE) G.retry[ri] = g;
+      if (ri != RT_NONE) { G.retry[ri] = g; G.retry_seed[ri] = seed; }
     }
   RT_SEG_END
   if (CNT) {

@@ -105,7 +105,8 @@ struct rt_context {
   GatherQ GQ;
   MeshQ MQ, MH, MS;
   uint32_t* d_list2 = nullptr;
-  uint32_t* d_gather_retry = nullptr;   // GatherP::retry
+  uint32_t* d_gather_retry = nullptr;   // GatherP::retry, retry_seed
+  float* d_gather_seed = nullptr;
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
   float4* d_path_rad = nullptr;
   uint32_t* d_pixels = nullptr;
@@ -1098,6 +1099,7 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.k = RP.photon_k;
   G.depth = photon_tree_depth(std::max(ctx->photons.count[0], ctx->photons.count[1]));
   G.retry = ctx->d_gather_retry;
+  G.retry_seed = ctx->d_gather_seed;
   G.retry_counts = retry_counts;
   if (G.hints) {
     LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
@@ -1184,6 +1186,7 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
   ctx->GQ.counts = nullptr;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_retry = (uint32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_seed = (float*)p;
   auto alloc_meshq = [&](MeshQ& q, double f, size_t item_bytes) {
     size_t sc = (fp.meshes && f > 0) ? cap_of(f) : 1;
     q.segcap = (uint32_t)sc;
