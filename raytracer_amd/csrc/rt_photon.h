@@ -294,9 +294,8 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
   const uint32_t hs = hm.stride;
   int sp = 0;
   uint32_t index = 1;
+  float4 pa = M.ph[2], pb = M.ph[3];
   for (;;) {
-    float4 pa = M.ph[2 * (size_t)index];
-    float4 pb = M.ph[2 * (size_t)index + 1];
     visits++;
     uint32_t next = 0;
     if ((int)index < M.half) {
@@ -307,13 +306,18 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
       next = dist > 0.0f ? 2 * index + 1 : 2 * index;
       if (dist * dist < bound) hm.walk[(sp++) * hs] = next ^ 1u;  // the sibling
     }
+    if (next == 0 && sp > 0) next = hm.walk[(--sp) * hs];
+    // the next node's photon is requested before this one is looked at: the walk is a chain of dependent fetches
+    float4 na = pa, nb = pb;
+    if (next != 0) {
+      na = M.ph[2 * (size_t)next];
+      nb = M.ph[2 * (size_t)next + 1];
+    }
     float dist2;
     if (photon_eligible(pa, pb, pos, normal, normScale, bound, dist2)) f(dist2, index, pa, pb);
-    if (next == 0) {
-      if (sp == 0) return;
-      next = hm.walk[(--sp) * hs];
-    }
+    if (next == 0) return;
     index = next;
+    pa = na; pb = nb;
   }
 }
 
