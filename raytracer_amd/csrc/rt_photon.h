@@ -336,6 +336,9 @@ struct Collected {
   uint32_t max_i;
 };
 
+// SORT_WIDE false: a bracket of more than RT_SEL photons is only counted (the hinted lookup rejects it afterwards), which
+// keeps the sorted list out of the walk's registers.
+template <bool SORT_WIDE>
 RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float lo, float hi, const HeapMem& hm, uint32_t& visits,
                            Collected& C) {
 #pragma unroll
@@ -368,6 +371,7 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
       return;
     }
     if (n_list < RT_SEL) { hm.list[(n_list++) * hs] = index; return; }
+    if (!SORT_WIDE) return;
     if (!spilled) {   // the list is full: sort what it holds, then carry on sorting in place
       spilled = true;
       for (uint32_t i = 0; i < RT_SEL; i++) {
@@ -493,7 +497,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
   }
   // ---- collect: powers below the bracket, the bracket's photons sorted by d' (ties in visiting order)
   Collected C;
-  photon_collect(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  photon_collect<true>(M, pos, normal, normScale, lo, hi, hm, visits, C);
   return photon_finish(M, pos, normal, normScale, r2, K, all, hm, visits, C, guess, hint);
 }
 
@@ -518,7 +522,7 @@ RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float
     hi = hint * (1.0f + delta);
   }
   Collected C;
-  photon_collect(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  photon_collect<false>(M, pos, normal, normScale, lo, hi, hm, visits, C);
   bool all = false;
   if (hi == r2) {
     if (C.n_all > K) { hint = -0.5f * r2; return false; }
