@@ -242,7 +242,10 @@ def main():
                 q.wait()
         torch.cuda.synchronize()
 
-    # one counted, untimed step: algorithmic work per step
+    if cfg.progressive_spp:
+        step()   # a frame's first pass: it leaves the per-pixel lookup hints that every later pass starts from
+        drain()
+    # one counted, untimed step: algorithmic work per step (of a later pass, where the frame is progressive)
     r.counters(enable=True, reset=True)
     step()
     drain()
