@@ -613,12 +613,22 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
         }
       } else {
         float gs = which ? guess[1] : guess[0];
+        bool done = false;
+        float hint = 0.0f;
         if (STAGE == 2) {
           float sd = G.retry_seed[seg_base_ + (uint32_t)seg_e];
-          if (sd > 0.0f) gs = sd;
+          if (sd > 0.0f) {
+            gs = sd;
+          } else {
+            // no hint when the first stage looked (a frame's first pass): another sample of the pixel may have left one since
+            hint = *hp;
+            if (hint > 0.0f) {
+              done = photon_estimate_hinted(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, hint, E);
+              if (!done) gs = -hint;
+            }
+          }
         }
-        float hint;
-        E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, gs, hint);
+        if (!done) E = photon_estimate(M, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), G.radius, ell, G.k, hm, visits, gs, hint);
         if (STAGE == 2) *hp = hint;
         if (which) guess[1] = gs; else guess[0] = gs;
         todo = false;
