@@ -45,9 +45,10 @@ struct DInstance {      // a node that carries a primitive (64 bytes); its chain
   int32_t depth;        // levels in the chain root .. this node
   int32_t parent_key;   // node index of the parent (identifies the chain prefix), -1 for a root-level instance
   int32_t xf_off;       // float offset into DScene::xf of this instance's chain: depth x { itm[12], tm[12] }, root first
-  int32_t pad0;
+  uint32_t shade_base;  // mesh instances: index of the mesh's first face record in DScene::shade (copied from the mesh so
+                        // that the shading attributes are one fetch away from the instance record)
   float wmin[3];        // padded world-space bounds (culling of mesh instances only)
-  float pad1;
+  uint32_t has_uvw;     // mesh instances: the mesh has texture coordinates
   float wmax[3];
   float pad2;
 };
@@ -55,7 +56,8 @@ struct DInstance {      // a node that carries a primitive (64 bytes); its chain
 struct DMesh {
   uint32_t node_base;   // float4 index of this mesh's first 64-byte BVH node in DScene::bvh
   uint32_t tri_base;    // float4 index of this mesh's first 48-byte triangle slot in DScene::tris
-  uint32_t nrm_base, nidx_base, uvw_base, uidx_base;  // element offsets into the attribute arrays
+  uint32_t shade_base;  // index of this mesh's first 80-byte face record in DScene::shade
+  uint32_t pad_[3];
   uint32_t root_ref;    // child reference of the root (leaf bit | first_slot<<3 | count, or internal node index)
   uint32_t has_uvw;
   float bounds[6];      // root box: min xyz, max xyz
@@ -88,10 +90,8 @@ struct DScene {
   const DMesh* meshes;
   const float4* bvh;
   const float4* tris;
-  const float* normals;
-  const uint32_t* nrm_idx;
-  const float* uvw;
-  const uint32_t* uvw_idx;
+  const float4* shade;  // per face, 5 float4: the three vertex normals and texture coordinates, indices resolved at commit
+                        // (n0 | t0.x) (n1 | t0.y) (n2 | t0.z) (t1 | t2.x) (t2.y t2.z - -)
   const DMaterial* materials;
   const DTexmap* texmaps;
   const DImage* images;
@@ -836,21 +836,15 @@ RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit)
       hn = v3(0.0f, 0.0f, 1.0f);
       uvw = v3((hp.x + 1.0f) * 0.5f, (hp.y + 1.0f) * 0.5f, 0.0f);
     } else {  // objects.cpp:303-320
-      const DMesh& M = S.meshes[I.mesh];
+      const float4* fr = S.shade + 5 * ((size_t)I.shade_base + B.mh.face);
+      const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
       float u = B.mh.u, v = B.mh.v, w = 1.0f - u - v;
       uvw = v3(0, 0, 0);
-      if (M.has_uvw) {
-        const uint32_t* ft = S.uvw_idx + M.uidx_base + 3 * B.mh.face;
-        const float* t0 = S.uvw + M.uvw_base + 3 * ft[0];
-        const float* t1 = S.uvw + M.uvw_base + 3 * ft[1];
-        const float* t2 = S.uvw + M.uvw_base + 3 * ft[2];
-        uvw = (v3(t0[0], t0[1], t0[2]) * w) + (v3(t1[0], t1[1], t1[2]) * u) + (v3(t2[0], t2[1], t2[2]) * v);
+      if (I.has_uvw) {
+        const float4 f3 = fr[3], f4 = fr[4];
+        uvw = (v3(f0.w, f1.w, f2.w) * w) + (v3(f3.x, f3.y, f3.z) * u) + (v3(f3.w, f4.x, f4.y) * v);
       }
-      const uint32_t* fn = S.nrm_idx + M.nidx_base + 3 * B.mh.face;
-      const float* n0 = S.normals + M.nrm_base + 3 * fn[0];
-      const float* n1 = S.normals + M.nrm_base + 3 * fn[1];
-      const float* n2 = S.normals + M.nrm_base + 3 * fn[2];
-      hn = normalized(w * v3(n0[0], n0[1], n0[2]) + u * v3(n1[0], n1[1], n1[2]) + v * v3(n2[0], n2[1], n2[2]));
+      hn = normalized(w * v3(f0.x, f0.y, f0.z) + u * v3(f1.x, f1.y, f1.z) + v * v3(f2.x, f2.y, f2.z));
       hp = p + d * best_t;
       front = dot(d, hn) < 0.0f;
       hit.face = (int32_t)B.mh.face;

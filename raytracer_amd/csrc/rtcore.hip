@@ -489,8 +489,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   std::vector<DMesh> meshes(sc->n_meshes);
   int max_mesh_depth = 0;
   std::vector<float4> bvh, tris;
-  std::vector<float> normals, uvw;
-  std::vector<uint32_t> nidx, uidx;
+  std::vector<float4> shade;   // DScene::shade
   for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
     const rt_mesh& m = sc->meshes[mi];
     if (!m.positions || !m.normals || !m.pos_idx || !m.nrm_idx || !m.bvh || m.n_bvh_nodes == 0 || (m.n_faces && !m.bvh_elements))
@@ -510,18 +509,31 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     D.root_ref = root;
     const rt_bvh_node& r = m.bvh[0];
     for (int k = 0; k < 3; k++) { D.bounds[k] = r.bmin[k]; D.bounds[3 + k] = r.bmax[k]; }
-    D.nrm_base = (uint32_t)normals.size();
-    normals.insert(normals.end(), m.normals, m.normals + 3 * (size_t)m.n_normals);
-    D.nidx_base = (uint32_t)nidx.size();
-    nidx.insert(nidx.end(), m.nrm_idx, m.nrm_idx + 3 * (size_t)m.n_faces);
-    D.has_uvw = (m.uvw && m.uvw_idx) ? 1 : 0;
-    if (D.has_uvw) {
-      D.uvw_base = (uint32_t)uvw.size();
-      uvw.insert(uvw.end(), m.uvw, m.uvw + 3 * (size_t)m.n_uvw);
-      D.uidx_base = (uint32_t)uidx.size();
-      uidx.insert(uidx.end(), m.uvw_idx, m.uvw_idx + 3 * (size_t)m.n_faces);
+    if ((shade.size() / 5 + (size_t)m.n_faces) >> 32) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^32 faces");
+    D.shade_base = (uint32_t)(shade.size() / 5);
+    const bool has_uvw = m.uvw && m.uvw_idx;
+    shade.resize(shade.size() + 5 * (size_t)m.n_faces);
+    for (size_t f = 0; f < (size_t)m.n_faces; f++) {
+      const float* n0 = m.normals + 3 * (size_t)m.nrm_idx[3 * f], *n1 = m.normals + 3 * (size_t)m.nrm_idx[3 * f + 1],
+                 * n2 = m.normals + 3 * (size_t)m.nrm_idx[3 * f + 2];
+      const float zero[3] = {0.0f, 0.0f, 0.0f};
+      const float* t0 = has_uvw ? m.uvw + 3 * (size_t)m.uvw_idx[3 * f] : zero;
+      const float* t1 = has_uvw ? m.uvw + 3 * (size_t)m.uvw_idx[3 * f + 1] : zero;
+      const float* t2 = has_uvw ? m.uvw + 3 * (size_t)m.uvw_idx[3 * f + 2] : zero;
+      float4* r = &shade[5 * ((size_t)D.shade_base + f)];
+      r[0] = make_float4(n0[0], n0[1], n0[2], t0[0]);
+      r[1] = make_float4(n1[0], n1[1], n1[2], t0[1]);
+      r[2] = make_float4(n2[0], n2[1], n2[2], t0[2]);
+      r[3] = make_float4(t1[0], t1[1], t1[2], t2[0]);
+      r[4] = make_float4(t2[1], t2[2], 0.0f, 0.0f);
     }
+    D.has_uvw = has_uvw ? 1 : 0;
   }
+  for (DInstance& I : inst)
+    if (I.prim == RT_PRIM_MESH) {
+      I.shade_base = meshes[I.mesh].shade_base;
+      I.has_uvw = meshes[I.mesh].has_uvw;
+    }
 
   // ---- materials, textures, lights
   std::vector<DMaterial> mtls;
@@ -589,10 +601,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, bvh, &D.bvh))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, tris, &D.tris))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, normals, &D.normals))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, nidx, &D.nrm_idx))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, uvw, &D.uvw))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, uidx, &D.uvw_idx))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, shade, &D.shade))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, mtls, &D.materials))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, tms, &D.texmaps))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, imgs, &D.images))) return rc;
