@@ -5,12 +5,13 @@
 //                    (SURVEY Q14).  Deposits are appended unordered with their (path, bounce) key; the host orders
 //                    them, keeps the first n per map (exactly the photons a sequential emitter would have kept,
 //                    photonmap.h:158-172) and balances the kd-tree (photonmap.h:176-264).
-//   k_photon_gather  PhotonMap::EstimateIrradiance<k> (photonmap.h:268-414) for the shade kernel's gather queue:
-//                    one lookup per lane, the reference's own kd-tree walk and max-heap, step for step — the
-//                    heap's first replacement evicts its root whatever the newcomer's distance (dist2[0] is only
-//                    refreshed on replacement, photonmap.h:383-397), so the result depends on the visiting order
-//                    and only the same walk reproduces it.  Heap and walk stack live in LDS, [entry][lane], which
-//                    is bank-conflict free for per-lane indices.
+//   k_photon_gather  PhotonMap::EstimateIrradiance<k> (photonmap.h:268-414) for the shade kernel's gather queue, one
+//                    lookup per lane.  The reference heap's first replacement evicts its root whatever the newcomer's
+//                    distance (dist2[0] is only refreshed on replacement, photonmap.h:383-397), so its result depends
+//                    on the visiting order; the kernel computes that same photon set by threshold counting over
+//                    fixed-radius walks of the same kd-tree plus a short walk in the reference's order (see "gather"
+//                    below), from per-pixel hints where it has them.  Walk stack and bracket list live in LDS,
+//                    [entry][lane], which is bank-conflict free for per-lane indices.
 #pragma once
 #include <vector>
 
@@ -183,11 +184,11 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 // The device computes exactly that set without the per-query heap (k = 128 entries x 8 bytes per lane is what capped the
 // heap kernel at two waves per CU and 8 G node visits/s): the (k+1)-th smallest d' is found by counting eligible
 // photons below 16 thresholds per fixed-radius walk of the same kd-tree (the bracket narrows 16x per walk, starting
-// with radius^2 / 4), the last walk sums the powers below the bracket and keeps the bracket's <= 16 photons sorted in
-// registers, and a walk in the reference's visiting order that stops at the first eligible photon beyond the k-th
-// distance decides the exception.  Per-lane memory is the kd walk stack only.  The photon SET is the reference's (equal
-// d' values among different photons are resolved by visiting order here and by heap history there); the power sum runs
-// in visiting order instead of heap order, i.e. irradiance agrees to float-sum reordering (tests: 2e-5 relative).
+// with radius^2 / 4), the last walk sums the powers below the bracket and notes the bracket's <= 16 photons in the
+// lane's LDS list (sorted after the walk), and a walk in the reference's visiting order that stops at the first
+// eligible photon beyond the k-th distance decides the exception.  The photon SET is the reference's (equal d' values
+// among different photons are resolved by visiting order here and by heap history there); the power sum runs in
+// visiting order instead of heap order, i.e. irradiance agrees to float-sum reordering (tests: 2e-5 relative).
 struct HeapMem {     // per-lane views of the lookup's LDS: entry i of this lane is at [i * stride]
   uint32_t* walk;    // kd walk stack: node index << 4 | split axis << 2 | state (pre-order walks: the node index alone)
   uint32_t* list;    // RT_SEL entries: the collecting walk's bracket photons in visiting order
