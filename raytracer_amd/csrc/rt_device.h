@@ -1052,8 +1052,13 @@ template <bool CNT>
 RT_DEV void mesh_walk_leaf_closest(const DScene& S, const MeshWalk& W, uint32_t ref, MeshHit& L, bool& found, Cnt<CNT>& cnt) {
   const float4* tris = S.tris + W.tri_base;
   uint32_t count = ref & 7u, first = (ref & 0x7fffffffu) >> 3;
+  if (count == 0) return;
+  // the next slot is requested before the current triangle is tested: the loop is not unrolled (1..4 slots), and a
+  // fetch per iteration would put a whole memory latency in front of every test
+  float4 a = tris[3 * first], b = tris[3 * first + 1], c = tris[3 * first + 2];
   for (uint32_t s = 0; s < count; s++) {
-    float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+    float4 na = a, nb = b, nc = c;
+    if (s + 1 < count) { na = tris[3 * (first + s + 1)]; nb = tris[3 * (first + s + 1) + 1]; nc = tris[3 * (first + s + 1) + 2]; }
     float t, u, v;
     cnt.tri();
     if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
@@ -1064,6 +1069,7 @@ RT_DEV void mesh_walk_leaf_closest(const DScene& S, const MeshWalk& W, uint32_t 
         }
       }
     }
+    a = na; b = nb; c = nc;
   }
 }
 // Leaf step of the any-hit walk: true when a triangle of leaf `ref` has t in (0.002, t_max) (objects.cpp:341-371).
@@ -1072,12 +1078,16 @@ RT_DEV bool mesh_walk_leaf_any(const DScene& S, const MeshWalk& W, uint32_t ref,
   const float4* tris = S.tris + W.tri_base;
   uint32_t count = ref & 7u, first = (ref & 0x7fffffffu) >> 3;
   bool occluded = false;
+  if (count == 0) return false;
+  float4 a = tris[3 * first], b = tris[3 * first + 1], c = tris[3 * first + 2];  // (fetch ahead, as above)
   for (uint32_t s = 0; s < count; s++) {
-    float4 a = tris[3 * (first + s)], b = tris[3 * (first + s) + 1], c = tris[3 * (first + s) + 2];
+    float4 na = a, nb = b, nc = c;
+    if (s + 1 < count) { na = tris[3 * (first + s + 1)]; nb = tris[3 * (first + s + 1) + 1]; nc = tris[3 * (first + s + 1) + 2]; }
     float t, u, v;
     cnt.tri();
     if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
       if (t > 0.002f && t < t_max) { occluded = true; break; }
+    a = na; b = nb; c = nc;
   }
   return occluded;
 }
