@@ -233,15 +233,17 @@ RT_DEV void primary_ray(const DScene& S, const PassP& P, const FrameBufs& F, uin
     if (hx > 1.0f) hx -= 1.0f;
     hy = S.halton[RT_H3 + (i & 127)] + ro;
     if (hy > 1.0f) hy -= 1.0f;
-    float discX = S.halton[RT_H5 + (i & 127)] + ro;   // :152-157
-    float discY = S.halton[RT_H7 + (i & 127)] + roy;
-    if (discX > 1.0f) discX -= 1.0f;
-    if (discY > 1.0f) discY -= 1.0f;
-    float r_ = sqrtf(discX);
-    float angle = two_pi_times(discY);
-    float lensU = r_ * P.dof * cosf(angle);
-    float lensV = r_ * P.dof * sinf(angle);
-    camOff = v3(lensU, lensV, 0.0f);
+    if (P.dof != 0.0f) {   // (a pinhole camera: the lens offset is +-0 and changes neither origin nor direction)
+      float discX = S.halton[RT_H5 + (i & 127)] + ro;   // :152-157
+      float discY = S.halton[RT_H7 + (i & 127)] + roy;
+      if (discX > 1.0f) discX -= 1.0f;
+      if (discY > 1.0f) discY -= 1.0f;
+      float r_ = sqrtf(discX);
+      float angle = two_pi_times(discY);
+      float lensU = r_ * P.dof * cosf(angle);
+      float lensV = r_ * P.dof * sinf(angle);
+      camOff = v3(lensU, lensV, 0.0f);
+    }
   }
   float pixX = -(P.ww / 2.0f) + ((P.ww * ((float)x + (1.0f / 2.0f) + hx) / P.camW));   // :147
   float pixY = (P.wh / 2.0f) - ((P.wh * ((float)y + (1.0f / 2.0f) + hy) / P.camH));    // :148
