@@ -913,11 +913,38 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
     smin = v3(wave_min(active ? fminf(o.x, e.x) : RT_BIG), wave_min(active ? fminf(o.y, e.y) : RT_BIG), wave_min(active ? fminf(o.z, e.z) : RT_BIG));
     smax = v3(wave_max(active ? fmaxf(o.x, e.x) : -RT_BIG), wave_max(active ? fmaxf(o.y, e.y) : -RT_BIG), wave_max(active ? fmaxf(o.z, e.z) : -RT_BIG));
   }
+#ifndef RT_EMU
+  // The cull of up to 64 table entries at once: lane l compares entry l's box with the wave's segment box, and the loop
+  // below runs over the survivors only (ascending, as before).  Entry by entry, every culled instance cost a scalar load
+  // and its latency; shadow rays cull most of the table.
+  unsigned long long live = ~0ull;
+  int live_base = -64;
+#endif
   for (int i = 0; i < S.n_inst; i++) {
+#ifndef RT_EMU
+    if (SPLIT) {
+      if (i >= live_base + 64) {
+        live_base = i;
+        const int li = i + (int)(threadIdx.x & 63u);
+        bool keep = false;
+        if (li < S.n_inst) {
+          const DInstance& J = S.inst[li];
+          keep = !(smin.x > J.wmax[0] || smax.x < J.wmin[0] || smin.y > J.wmax[1] || smax.y < J.wmin[1] || smin.z > J.wmax[2] ||
+                   smax.z < J.wmin[2]);
+        }
+        live = __ballot(keep);
+      }
+      unsigned long long rest = live >> (unsigned)(i - live_base);
+      if (rest == 0ull) { i = live_base + 63; continue; }       // nothing left in this group of 64  [wave-uniform]
+      i += __ffsll((long long)rest) - 1;                         // the next survivor
+    }
+#endif
     RT_UTYPE(DInstance)* I = inst + i;
+#ifdef RT_EMU
     if (SPLIT && (smin.x > I->wmax[0] || smax.x < I->wmin[0] || smin.y > I->wmax[1] || smax.y < I->wmin[1] || smin.z > I->wmax[2] ||
                   smax.z < I->wmin[2]))
-      continue;  // [wave-uniform]
+      continue;
+#endif
     int prim = I->prim;
     V3 p, d;
     ray_to_instance(I, xf, o, dir, pr, p, d);
