@@ -63,6 +63,18 @@ struct DMesh {
   float bounds[6];      // root box: min xyz, max xyz
 };
 
+struct DMeshInst {      // what the second-phase walk needs to enter a mesh instance, in one 80-byte record (instead of
+  float wmin[3];        // the index list -> instance record -> mesh record chain of dependent fetches)
+  int32_t inst;         // index into DScene::inst
+  float wmax[3];        // padded world box, as DInstance
+  int32_t depth;
+  float bounds[6];      // the mesh's root box, as DMesh
+  int32_t xf_off;
+  uint32_t root_ref;
+  uint32_t node_base, tri_base;
+  uint32_t pad_[2];
+};
+
 struct DTexColor { float v[3]; int32_t map; };
 struct DTexFloat { float v; int32_t map; };
 struct DTexmap {
@@ -102,6 +114,7 @@ struct DScene {
   int32_t n_inst, n_lights, n_materials, n_gloss;
   DTexColor background, environment;
   const int32_t* minst;  // indices (into inst) of the mesh instances, depth-first order
+  const DMeshInst* minst_rec;  // ... and their records for the second-phase walk
   int32_t n_minst;
   int32_t use_tlas;      // the scene has enough instances for the instance BVH below to pay (rt_scene_commit)
   const float4* tlas;    // BVH over the instances' padded world boxes, 64-byte nodes as DScene::bvh
@@ -999,26 +1012,26 @@ RT_DEV bool ref_is_leaf(uint32_t r) { return (r & RT_LEAF) && r != RT_NOREF; }
 template <bool CNT>
 RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, float t_limit, MeshWalk& W, Cnt<CNT>& cnt) {
   while (W.mi < S.n_minst) {
-    int ii = S.minst[W.mi++];
-    const DInstance& I = S.inst[ii];
+    const DMeshInst& R = S.minst_rec[W.mi++];
     float tm;
-    if (!box_test(o, winv, I.wmin[0], I.wmin[1], I.wmin[2], I.wmax[0], I.wmax[1], I.wmax[2], tm)) continue;
+    if (!box_test(o, winv, R.wmin[0], R.wmin[1], R.wmin[2], R.wmax[0], R.wmax[1], R.wmax[2], tm)) continue;
     if (tm > prune_bound(t_limit)) continue;  // entered beyond the best hit so far / the light: cannot matter
-    const float* chain = S.xf + I.xf_off;
+    const float* chain = S.xf + R.xf_off;
     V3 p = o, d = dir;
-    for (int k = 0; k < I.depth; k++) {
+    for (int k = 0; k < R.depth; k++) {
       V3 np = xf_point(chain + 24 * k, p);
       V3 nd = xf_dir(chain + 24 * k, d);
       p = np; d = nd;
     }
     cnt.inst();
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const DMesh& M = S.meshes[I.mesh];
     bool fast = inv_is_finite(inv);
     cnt.node();
-    bool hit = fast ? box_test_fast(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)
-                    : box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm);
+    bool hit = fast ? box_test_fast(p, inv, R.bounds[0], R.bounds[1], R.bounds[2], R.bounds[3], R.bounds[4], R.bounds[5], tm)
+                    : box_test(p, inv, R.bounds[0], R.bounds[1], R.bounds[2], R.bounds[3], R.bounds[4], R.bounds[5], tm);
     if (!hit) continue;
+    const int ii = R.inst;
+    const DMeshInst& M = R;
     W.p = p; W.d = d; W.inv = inv; W.fast = fast;
     W.cur = M.root_ref; W.pend = 0; W.sp = 0; W.inst = ii;
     W.node_base = M.node_base; W.tri_base = M.tri_base;

@@ -612,6 +612,18 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   for (size_t i = 0; i < inst.size(); i++)
     if (inst[i].prim == RT_PRIM_MESH) minst.push_back((int32_t)i);
   if ((rc = upload(ctx, ctx->scene_mem, minst, &D.minst))) return rc;
+  std::vector<DMeshInst> minst_rec(minst.size());
+  for (size_t k = 0; k < minst.size(); k++) {
+    const DInstance& I = inst[minst[k]];
+    const DMesh& M = meshes[I.mesh];
+    DMeshInst& R = minst_rec[k];
+    std::memset(&R, 0, sizeof R);
+    for (int c = 0; c < 3; c++) { R.wmin[c] = I.wmin[c]; R.wmax[c] = I.wmax[c]; }
+    for (int c = 0; c < 6; c++) R.bounds[c] = M.bounds[c];
+    R.inst = minst[k]; R.depth = I.depth; R.xf_off = I.xf_off;
+    R.root_ref = M.root_ref; R.node_base = M.node_base; R.tri_base = M.tri_base;
+  }
+  if ((rc = upload(ctx, ctx->scene_mem, minst_rec, &D.minst_rec))) return rc;
   D.n_minst = (int32_t)minst.size();
   ctx->n_minst = D.n_minst;
   // instance BVH: pays once the wave-uniform table loop is longer than a short divergent walk; the nested mesh walk of
