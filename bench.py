@@ -206,10 +206,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # BENCH_REHEARSE_GLOO=1: every rank on GPU 0 with the gloo backend — a rehearsal of the N > 1 plumbing on a one-GPU
+    # box (its number means nothing: the ranks share the card and the exchange is staged through the host)
+    rehearse = world > 1 and os.environ.get("BENCH_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    stat_dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
     from raytracer_amd import Renderer, Scene, distributed
     scene = cfg.scene()
@@ -270,8 +279,8 @@ def main():
     prof = r.profile()
     r.profile(enable=False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    rays = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
+    rays = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)

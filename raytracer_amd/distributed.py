@@ -55,6 +55,17 @@ def reduce_accumulators(accum, group=None, dst=0, sums_only=True, async_op=False
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return PendingReduce(accum, None, None, True)
     is_dst = dist.get_rank(group) == dst
+    if accum.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-rank path on a box without one GPU per rank (gloo does not reduce device tensors):
+        # staged through the host, blocking
+        host = (accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4].contiguous() if sums_only else accum).cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if is_dst:
+            if sums_only:
+                accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4] = host.to(accum.device)
+            else:
+                accum.copy_(host)
+        return PendingReduce(accum, None, None, is_dst)
     if sums_only:
         packed = accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4].contiguous()
         work = dist.reduce(packed, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True)
