@@ -110,6 +110,28 @@ def test_png_roundtrip(tmp_path):
     assert np.array_equal(back, np.asarray(pal.convert("RGB")))
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference checkout not present")
+def test_every_bundled_texture_decodes_like_lct_rgb():
+    """TextureFile::Load decodes PNGs with lodepng to LCT_RGB, 8 bit (texture.cpp:86).  The reference's textures are
+    palettised at 2 / 4 / 8 bits, RGBA, grey and 1-bit grey; each must decode to the RGB an independent decoder gives."""
+    from PIL import Image
+    host = _ffi.load_host()
+    files = sorted(glob.glob(os.path.join(REF_SCENES, "**", "*.png"), recursive=True))
+    assert len(files) > 100
+    kinds = set()
+    for f in files:
+        ptr = C.POINTER(C.c_uint8)()
+        w, h = C.c_int(), C.c_int()
+        assert host.rth_read_image_rgb(f.encode(), C.byref(ptr), C.byref(w), C.byref(h)) == 0, f
+        got = np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+        host.rth_free(ptr)
+        im = Image.open(f)
+        kinds.add(im.mode)
+        ref = np.asarray(im.convert("RGBA").convert("RGB") if im.mode in ("P", "RGBA", "LA", "PA") else im.convert("RGB"))
+        assert got.shape == ref.shape and np.array_equal(got, ref), f
+    assert {"P", "RGBA"} <= kinds
+
+
 def _check_bvh(mesh):
     nf = mesh.n_faces
     pos = np.ctypeslib.as_array(mesh.positions, shape=(mesh.n_positions, 3))
