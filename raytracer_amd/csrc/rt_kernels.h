@@ -432,7 +432,9 @@ __device__ unsigned long long g_walk_stats[16];
 #define RT_NODE_BATCH 4
 #endif
 #ifndef RT_LEAF_MIN
-#define RT_LEAF_MIN 24u     // parked leaves that trigger a leaf step while enough lanes still stand at inner nodes
+#define RT_LEAF_MIN 12u     // parked leaves that trigger a leaf step while enough lanes still stand at inner nodes
+                            // (24 before the leaf steps fetched one slot ahead; now 8 / 12 / 16 / 24 -> C2 20.32 / 20.24 / 20.28 / 20.45 ms,
+                            //  C5 880 / - / 884 / 895 ms)
 #endif
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 5          // measured with the scene-sized stack: 4 -> 7.24 ms, 5 -> 6.58 ms, 6 -> 7.65 ms (spills) per C2 step
