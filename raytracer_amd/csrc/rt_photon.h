@@ -572,6 +572,7 @@ struct GatherP {
   int32_t k;
   int32_t depth;   // walk stack entries per lane
   uint32_t n_pix;  // pixels of the pass (path slot -> pixel)
+  uint32_t n_hint_px;  // W * H: entries per map of `hints`
   float* hints;    // [W * H][2]: per pixel and map, the (k+1)-th smallest d' of the last lookup (0: none); null without
                    // hints (STAGE 0)
   uint32_t* retry;          // STAGE 1 -> 2: queue entries still to do, segmented like the queue itself
@@ -583,6 +584,24 @@ struct GatherP {
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
 #endif
+#ifndef RT_HINT_CELLS
+#define RT_HINT_CELLS 12.0f   // hint grid cells per search radius (secondary lookups)
+#endif
+// Where a lookup's hint lives.  Primary hits (global map): the pixel — its samples look up within a pixel footprint of
+// each other.  Secondary hits (caustics map) land wherever the reflected / refracted ray goes, so they share hints by
+// place instead: a hash of the lookup's grid cell (a twelfth of the search radius) and the side its normal faces, into
+// the same table.  Collisions only cost a walk.
+RT_DEV size_t gather_hint_slot(const GatherP& G, const FrameBufs& F, uint32_t slot, uint32_t which, V3 pos, V3 n) {
+  if (which == 0) return 2 * (size_t)F.pixels[slot % G.n_pix];
+  const float inv_cell = RT_HINT_CELLS / G.radius;
+  int ix = (int)floorf(pos.x * inv_cell), iy = (int)floorf(pos.y * inv_cell), iz = (int)floorf(pos.z * inv_cell);
+  float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+  uint32_t side = ax >= ay && ax >= az ? (n.x < 0.0f ? 0u : 1u) : (ay >= az ? (n.y < 0.0f ? 2u : 3u) : (n.z < 0.0f ? 4u : 5u));
+  uint32_t h = (uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u ^ (uint32_t)iz * 83492791u ^ side * 0x9e3779b9u;
+  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+  return 2 * (size_t)(h % G.n_hint_px) + 1;
+}
+
 // STAGE 0: every lookup from scratch (no hint buffer).  With hints the queue is taken in two stages, because a wave is
 // as slow as its slowest lane: STAGE 1 tries every hinted lookup (one walk + the exception test) and lists the ones
 // without a hint or whose bracket missed; STAGE 2 runs the listed lookups from scratch, packed densely into waves.
@@ -603,7 +622,7 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
       const float ell = which ? G.ellipticity[1] : G.ellipticity[0];
       // what the last lookup of this pixel into this map found (an earlier pass of the frame, or another sample of the
       // pixel in this pass): a plain load and store, any value is only a hint
-      float* hp = STAGE == 0 ? nullptr : G.hints + 2 * (size_t)F.pixels[__float_as_uint(a.w) % G.n_pix] + which;
+      float* hp = STAGE == 0 ? nullptr : G.hints + gather_hint_slot(G, F, __float_as_uint(a.w), which, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
       V3 E = v3(0, 0, 0);
       if (STAGE == 1) {
         float hint = *hp;

@@ -1111,6 +1111,7 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.n_pix = P.n_pix;
   ensure_gather_hints(ctx, (size_t)P.W * (size_t)P.H);
   G.hints = ctx->d_gather_hints;
+  G.n_hint_px = (uint32_t)ctx->gather_hint_px;
   if (const char* e = std::getenv("RT_GATHER_HINTS")) if (std::atoi(e) == 0) G.hints = nullptr;  // developer knob (tests run both)
   G.map[0] = photon_dmap(ctx->photons, 0);
   G.map[1] = photon_dmap(ctx->photons, 1);
