@@ -594,7 +594,8 @@ struct GatherP {
 RT_DEV size_t gather_hint_slot(const GatherP& G, const FrameBufs& F, uint32_t slot, uint32_t which, V3 pos, V3 n) {
   if (which == 0) return 2 * (size_t)F.pixels[slot % G.n_pix];
   const float inv_cell = RT_HINT_CELLS / G.radius;
-  int ix = (int)floorf(pos.x * inv_cell), iy = (int)floorf(pos.y * inv_cell), iz = (int)floorf(pos.z * inv_cell);
+  auto cell = [&](float x) { return (int)fminf(fmaxf(floorf(x * inv_cell), -1.0e9f), 1.0e9f); };  // (any value will do far out)
+  int ix = cell(pos.x), iy = cell(pos.y), iz = cell(pos.z);
   float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
   uint32_t side = ax >= ay && ax >= az ? (n.x < 0.0f ? 0u : 1u) : (ay >= az ? (n.y < 0.0f ? 2u : 3u) : (n.z < 0.0f ? 4u : 5u));
   uint32_t h = (uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u ^ (uint32_t)iz * 83492791u ^ side * 0x9e3779b9u;
