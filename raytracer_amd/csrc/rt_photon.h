@@ -573,6 +573,7 @@ struct GatherP {
   int32_t depth;   // walk stack entries per lane
   uint32_t n_pix;  // pixels of the pass (path slot -> pixel)
   uint32_t n_hint_px;  // W * H: entries per map of `hints`
+  int32_t pilot;       // STAGE 1: 0 every lookup; 1 list the pilot lookups only; 2 every lookup but the pilots
   float* hints;    // [W * H][2]: per pixel and map, the (k+1)-th smallest d' of the last lookup (0: none); null without
                    // hints (STAGE 0)
   uint32_t* retry;          // STAGE 1 -> 2: queue entries still to do, segmented like the queue itself
@@ -616,7 +617,15 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
     if (STAGE == 2 && seg_valid) g = G.retry[g];
     bool todo = seg_valid;   // (every lane reaches the append below)
     float seed = 0.0f;       // STAGE 1 -> 2: a squared radius to start the counting walks from
-    if (seg_valid) {
+    bool mine = seg_valid;
+    if (STAGE == 1 && G.pilot != 0 && seg_valid) {
+      // a frame's first pass has no hints yet: the lookups of every eighth camera sample go first, from scratch
+      // (pilot 1: only they are listed), and leave hints for all the others (pilot 2: everything but them)
+      const bool is_pilot = ((__float_as_uint(Q.a[g].w) / G.n_pix) & 7u) == 0u;
+      mine = G.pilot == 2 ? !is_pilot : false;
+      todo = G.pilot == 1 ? is_pilot : todo && mine;
+    }
+    if (mine) {
       float4 a = Q.a[g], b = Q.b[g], c = Q.c[g];
       uint32_t which = __float_as_uint(b.w) & 1u;
       const DPhotonMap& M = which ? G.map[1] : G.map[0];

@@ -127,6 +127,7 @@ struct rt_context {
   PhotonState photons;
   float* d_gather_hints = nullptr;   // [W * H][2], see GatherP::hints; lives as long as the frame size
   size_t gather_hint_px = 0;
+  bool gather_hints_cold = true;     // nothing in the table yet: the next pass runs its pilot lookups first
 
   bool counters_on = false, profile_on = false;
   uint64_t host_paths = 0;
@@ -425,6 +426,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   ctx->fan_valid = false;
   photon_state_free(ctx->photons);
   if (ctx->d_gather_hints) HIP_TRY(hipMemsetAsync(ctx->d_gather_hints, 0, ctx->gather_hint_px * 2 * sizeof(float), ctx->stream));
+  ctx->gather_hints_cold = true;
 
   // ---- nodes and instances
   for (uint32_t i = 0; i < sc->n_nodes; i++) {
@@ -1102,6 +1104,7 @@ void ensure_gather_hints(rt_context* ctx, size_t npx) {
   if (hipMemsetAsync(p, 0, npx * 2 * sizeof(float), ctx->stream) != hipSuccess) { (void)hipFree(p); return; }
   ctx->d_gather_hints = (float*)p;
   ctx->gather_hint_px = npx;
+  ctx->gather_hints_cold = true;
 }
 
 template <bool CNT>
@@ -1123,7 +1126,17 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.retry = ctx->d_gather_retry;
   G.retry_seed = ctx->d_gather_seed;
   G.retry_counts = retry_counts;
-  if (G.hints) {
+  G.pilot = 0;
+  if (G.hints && ctx->gather_hints_cold) {
+    // no hints yet (first pass after a commit): pilot lookups from scratch, then the rest from the hints they leave
+    G.pilot = 1;
+    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
+    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+    (void)hipMemsetAsync(retry_counts, 0, CNT_SLAB * sizeof(uint32_t), ctx->stream);
+    G.pilot = 2;
+    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
+    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+  } else if (G.hints) {
     LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
     LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
   } else {
@@ -1372,6 +1385,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     std::swap(Qc, Qn);
     ub *= branch;
   }
+  if (photons && !P.discard) ctx->gather_hints_cold = false;   // (a sizing pass covers a pixel subset only)
   {
     Timer t(ctx, RT_K_ACCUM);
     LAUNCH(k_accumulate, P.n_pix, P, F);
