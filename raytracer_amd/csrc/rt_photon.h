@@ -514,7 +514,7 @@ RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float
   const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
-  const float delta = fminf(0.25f, 5.0f / (float)(K + 1));   // about 10 photons in the bracket
+  const float delta = fminf(0.25f, RT_HINT_HALF / (float)(K + 1));   // about 2 x RT_HINT_HALF photons in the bracket
   float lo, hi;
   if (hint * (1.0f + delta) >= r2) {
     lo = hi = r2;        // expect at most k photons within the radius (the bracket may not reach beyond it)
@@ -584,6 +584,9 @@ struct GatherP {
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
+#endif
+#ifndef RT_HINT_HALF
+#define RT_HINT_HALF 4.0f   // C4 gather with 2 / 3 / 3.5 / 4 / 5 / 6: 47.3 / 43.7 / 42.6 / 39.7 / 41.4 / 46.7 ms
 #endif
 #ifndef RT_HINT_CELLS
 #define RT_HINT_CELLS 12.0f   // hint grid cells per search radius (secondary lookups)
