@@ -326,6 +326,9 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
 #define RT_TEST_NO_EVICT_RULE 0   // tests build a variant with 1 to prove that the exception below is exercised
 #endif
 #define RT_SEL 16   // thresholds per counting walk = photons kept sorted by the collecting walk
+#ifndef RT_HINT_HALF
+#define RT_HINT_HALF 4.0f   // half-width of a hinted bracket in photons; C4 gather with 2 / 3 / 3.5 / 4 / 5 / 6: 47.3 / 43.7 / 42.6 / 39.7 / 41.4 / 46.7 ms
+#endif
 
 // What the collecting walk over the bracket [lo, hi) leaves behind.
 struct Collected {
@@ -584,9 +587,6 @@ struct GatherP {
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
-#endif
-#ifndef RT_HINT_HALF
-#define RT_HINT_HALF 4.0f   // C4 gather with 2 / 3 / 3.5 / 4 / 5 / 6: 47.3 / 43.7 / 42.6 / 39.7 / 41.4 / 46.7 ms
 #endif
 #ifndef RT_HINT_CELLS
 #define RT_HINT_CELLS 12.0f   // hint grid cells per search radius (secondary lookups)
