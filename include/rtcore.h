@@ -307,6 +307,17 @@ int rt_profile_enable(rt_context* ctx, int enable);
 int rt_profile_reset(rt_context* ctx);
 int rt_profile_get(rt_context* ctx, rt_profile* out);
 
+/* Developer knobs of one context (the reference's counterparts are compile-time constants, raytracer.h:17-23): "tlas_min"
+ * (instances from which the instance BVH replaces the scene-graph table walk; applies at the next rt_scene_commit),
+ * "gather_hints" (0: every photon lookup from scratch), "frame_gb" (stage-queue memory of one pass), "fan_scale" (scales the
+ * measured queue sizing; tests force the overflow path with it), "timing".  Their initial values come from the environment
+ * variables RT_TLAS_MIN / RT_GATHER_HINTS / RT_FRAME_GB / RT_TEST_FAN_SCALE / RT_TIMING, read once by rt_context_create. */
+int rt_set_option(rt_context* ctx, const char* name, double value);
+/* Number of device allocations (hipMalloc) made so far on behalf of this context: the entry points keep their device
+ * buffers in the context and grow them only, so a steady-state caller sees this stand still (no counterpart in the
+ * reference, whose renderer allocates per render, RayTracer.cpp:29-38). */
+int rt_debug_alloc_count(rt_context* ctx, uint64_t* n);
+
 /* Fills params with the reference's defaults (raytracer.h:17-23, renderer.h:172-174). */
 void rt_render_params_default(rt_render_params* params);
 

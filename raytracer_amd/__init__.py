@@ -158,9 +158,14 @@ class Renderer:
         h = params.height if params.height > 0 else self.scene.height
         return w, h
 
+    def _join(self):
+        """A render still in flight writes into the current renderImage's buffers: wait for it before they are replaced."""
+        self._lib.rt_render_wait(self._ctx)   # (its status belongs to that render's own StopRender)
+
     def BeginRender(self, params=None):
         params = params or self.params
         w, h = self._dims(params)
+        self._join()
         self.renderImage = RenderImage(w, h)
         self._fb = self.renderImage.framebuffer()
         self._check(self._lib.rt_render_begin(self._ctx, C.byref(params), C.byref(self._fb)), "rt_render_begin")
@@ -170,6 +175,11 @@ class Renderer:
         self._check(self._lib.rt_render_poll(self._ctx, C.byref(done), C.byref(fin)), "rt_render_poll")
         return done.value
 
+    def IsRenderDone(self):
+        done, fin = C.c_int64(), C.c_int()
+        self._check(self._lib.rt_render_poll(self._ctx, C.byref(done), C.byref(fin)), "rt_render_poll")
+        return bool(fin.value)
+
     def StopRender(self):
         self._check(self._lib.rt_render_wait(self._ctx), "rt_render_wait")
         return self.renderImage
@@ -178,6 +188,7 @@ class Renderer:
         """Blocking BeginRender + StopRender."""
         params = params or self.params
         w, h = self._dims(params)
+        self._join()
         self.renderImage = RenderImage(w, h)
         fb = self.renderImage.framebuffer()
         self._check(self._lib.rt_render(self._ctx, C.byref(params), C.byref(fb)), "rt_render")
@@ -246,10 +257,20 @@ class Renderer:
 
     def resolve(self, params, d_accum_ptr):
         w, h = self._dims(params)
+        self._join()
         self.renderImage = RenderImage(w, h)
         fb = self.renderImage.framebuffer()
         self._check(self._lib.rt_resolve(self._ctx, C.byref(params), C.c_void_p(d_accum_ptr), C.byref(fb)), "rt_resolve")
         return self.renderImage
+
+    def set_option(self, name, value):
+        """Developer knobs of this context (rt_set_option): tlas_min, gather_hints, frame_gb, fan_scale, timing."""
+        self._check(self._lib.rt_set_option(self._ctx, name.encode(), float(value)), "rt_set_option")
+
+    def alloc_count(self):
+        n = C.c_uint64()
+        self._check(self._lib.rt_debug_alloc_count(self._ctx, C.byref(n)), "rt_debug_alloc_count")
+        return n.value
 
     def counters(self, enable=None, reset=False):
         if enable is not None:

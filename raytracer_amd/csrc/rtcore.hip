@@ -79,10 +79,27 @@ T* dptr(const DevMem& m) { return (T*)m.p; }
 
 }  // namespace
 
+// Developer knobs (tests force both sides of a threshold with them).  Read from the environment ONCE, when the context is
+// created, and settable per context through rt_set_option; nothing on the render path calls getenv.
+struct Options {
+  double tlas_min = RT_TLAS_MIN;   // "tlas_min"     RT_TLAS_MIN      instances from which the instance BVH is used
+  double gather_hints = 1;         // "gather_hints" RT_GATHER_HINTS  0: every photon lookup from scratch
+  double frame_gb = 0;             // "frame_gb"     RT_FRAME_GB      stage-queue memory of one pass (0: frame_mem_mb / 32 GB)
+  double fan_scale = 1;            // "fan_scale"    RT_TEST_FAN_SCALE  scales the measured queue sizing (tests: forces overflow)
+  double timing = 0;               // "timing"       RT_TIMING        host-side phases of the photon build on stderr
+};
+
+// grow-only device buffers the entry points reuse from call to call (no hipMalloc / hipFree in the steady state)
+enum { SC_ACCUM = 0, SC_RES_RGB, SC_RES_RAD, SC_RES_CNT, SC_API_A, SC_API_B, SC_API_C, SC_DN_RGB, SC_DN_A, SC_DN_B, SC_DN_ALB, SC_DN_NRM,
+       SC_PH_REC0, SC_PH_REC1, SC_PH_KEY0, SC_PH_KEY1, SC_PH_MISC, SC_PH_PL, SC_COUNT };
+
 struct rt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  Options opt;
+  DevMem scratch[SC_COUNT];
+  uint64_t n_allocs = 0;   // hipMalloc calls made on behalf of this context (rt_debug_alloc_count)
   int max_blocks = 2048, max_blocks_trace = 1024;
   int n_cus = 256;
   size_t trace_lds = (size_t)RT_STACK * RT_BLOCK * 4;   // dynamic LDS of the traversal kernels: stack entries of the scene x block
@@ -149,10 +166,31 @@ int alloc_dev(rt_context* ctx, std::vector<DevMem>& pool, size_t bytes, void** o
   DevMem m;
   if (bytes == 0) bytes = 16;
   HIP_TRY(hipMalloc(&m.p, bytes));
+  ctx->n_allocs++;
   m.bytes = bytes;
   pool.push_back(m);
   *out = m.p;
   return RT_OK;
+}
+// The context's grow-only buffer `slot`, at least `bytes` large.  (Callers have synchronised the stream before a buffer
+// can be replaced: every entry point that uses one ends with a stream synchronisation.)
+int scratch_dev(rt_context* ctx, int slot, size_t bytes, void** out) {
+  DevMem& m = ctx->scratch[slot];
+  if (bytes == 0) bytes = 16;
+  if (!m.p || m.bytes < bytes) {
+    m.release();
+    size_t want = bytes + bytes / 8;   // headroom: a slightly larger batch next time does not reallocate
+    HIP_TRY(hipMalloc(&m.p, want));
+    ctx->n_allocs++;
+    m.bytes = want;
+  }
+  *out = m.p;
+  return RT_OK;
+}
+// An asynchronous render (rt_render_begin) owns the context's stream and frame resources until it has finished: every
+// other entry point waits for it first.
+void quiesce(rt_context* ctx) {
+  if (ctx->worker.joinable()) ctx->worker.join();
 }
 template <class T>
 int upload(rt_context* ctx, std::vector<DevMem>& pool, const std::vector<T>& v, const T** out) {
@@ -393,7 +431,34 @@ int rt_context_create(int device_id, rt_context** out) {
   if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
   ctx->d_counters = (DCounters*)p;
   (void)hipMemset(p, 0, sizeof(DCounters));
+  // developer knobs: the environment is read here and nowhere else
+  auto env = [](const char* name, double& v) { if (const char* e = std::getenv(name)) v = std::atof(e); };
+  env("RT_TLAS_MIN", ctx->opt.tlas_min);
+  env("RT_GATHER_HINTS", ctx->opt.gather_hints);
+  env("RT_FRAME_GB", ctx->opt.frame_gb);
+  env("RT_TEST_FAN_SCALE", ctx->opt.fan_scale);
+  if (std::getenv("RT_TIMING")) ctx->opt.timing = 1;
   *out = ctx;
+  return RT_OK;
+}
+
+int rt_set_option(rt_context* ctx, const char* name, double value) {
+  if (!ctx || !name) return RT_ERR_INVALID;
+  quiesce(ctx);
+  const std::string n(name);
+  if (n == "tlas_min") ctx->opt.tlas_min = value;            // takes effect at the next rt_scene_commit
+  else if (n == "gather_hints") ctx->opt.gather_hints = value;
+  else if (n == "frame_gb") ctx->opt.frame_gb = value;
+  else if (n == "fan_scale") { ctx->opt.fan_scale = value; ctx->fan_valid = false; }
+  else if (n == "timing") ctx->opt.timing = value;
+  else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
+  return RT_OK;
+}
+
+int rt_debug_alloc_count(rt_context* ctx, uint64_t* n) {
+  if (!ctx || !n) return RT_ERR_INVALID;
+  quiesce(ctx);
+  *n = ctx->n_allocs;
   return RT_OK;
 }
 
@@ -404,6 +469,7 @@ void rt_context_destroy(rt_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   free_pool(ctx->scene_mem);
   free_pool(ctx->frame_mem);
+  for (auto& m : ctx->scratch) m.release();
   photon_state_free(ctx->photons);
   if (ctx->d_gather_hints) (void)hipFree(ctx->d_gather_hints);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -418,8 +484,8 @@ const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str()
 int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if (!ctx) return RT_ERR_INVALID;
   if (!sc || !sc->nodes || sc->n_nodes == 0) return fail(ctx, RT_ERR_INVALID, "scene has no nodes");
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->worker.joinable()) ctx->worker.join();
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   free_pool(ctx->scene_mem);
   ctx->has_scene = false;
@@ -632,8 +698,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   // the one-phase callers (rt_trace_closest / rt_trace_any, photons) shares the per-lane stack with it
   D.use_tlas = 0;
   int tlas_depth = 0;
-  size_t tlas_min = RT_TLAS_MIN;
-  if (const char* e = std::getenv("RT_TLAS_MIN")) tlas_min = (size_t)std::atoll(e);  // developer knob (tests force both paths)
+  const size_t tlas_min = (size_t)std::max(0.0, ctx->opt.tlas_min);   // (developer knob: tests force both paths)
   if (inst.size() >= tlas_min && inst.size() >= 2) {
     TlasBuild tb(inst);
     std::vector<int32_t> ids(inst.size());
@@ -672,48 +737,40 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
 
 int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
   if (n == 0) return RT_OK;
   if (!rays || !hits || n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "bad ray batch");
   static_assert(sizeof(HitOut) == sizeof(rt_hit), "rt_hit layout");
   HIP_TRY(hipSetDevice(ctx->device));
-  std::vector<DevMem> tmp;
   void *d_r, *d_h;
   int rc;
-  if ((rc = alloc_dev(ctx, tmp, n * sizeof(rt_ray), &d_r)) || (rc = alloc_dev(ctx, tmp, n * sizeof(rt_hit), &d_h))) { free_pool(tmp); return rc; }
-  hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    LAUNCH_T(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(hits, d_h, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  free_pool(tmp);
-  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  if ((rc = scratch_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = scratch_dev(ctx, SC_API_B, n * sizeof(rt_hit), &d_h))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream));
+  LAUNCH_T(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hits, d_h, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
 int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
   if (n == 0) return RT_OK;
   if (!rays || !occluded || n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "bad ray batch");
   HIP_TRY(hipSetDevice(ctx->device));
-  std::vector<DevMem> tmp;
   void *d_r, *d_t = nullptr, *d_o;
   int rc;
-  if ((rc = alloc_dev(ctx, tmp, n * sizeof(rt_ray), &d_r)) || (rc = alloc_dev(ctx, tmp, n, &d_o))) { free_pool(tmp); return rc; }
-  if (t_max && (rc = alloc_dev(ctx, tmp, n * sizeof(float), &d_t))) { free_pool(tmp); return rc; }
-  hipError_t e = hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && t_max) e = hipMemcpyAsync(d_t, t_max, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    LAUNCH_T(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(occluded, d_o, n, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  free_pool(tmp);
-  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  if ((rc = scratch_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = scratch_dev(ctx, SC_API_B, n, &d_o))) return rc;
+  if (t_max && (rc = scratch_dev(ctx, SC_API_C, n * sizeof(float), &d_t))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream));
+  if (t_max) HIP_TRY(hipMemcpyAsync(d_t, t_max, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  LAUNCH_T(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(occluded, d_o, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
@@ -901,7 +958,7 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
   kept[0].reserve(n);
   kept[1].reserve(n);
   uint32_t emitted = 0;
-  const bool timing = std::getenv("RT_TIMING") != nullptr;   // developer aid: host-side phases of the build on stderr
+  const bool timing = ctx->opt.timing != 0;   // developer aid: host-side phases of the build on stderr
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_start = now(), t_kernel = 0, t_copy = 0, t_sort = 0;
   int n_batches = 0;
@@ -1070,25 +1127,18 @@ int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* 
   if (k <= 0 || k > RT_PHOTON_MAX_K) return fail(ctx, RT_ERR_UNSUPPORTED, "k must be in 1..256");
   if (n == 0) return RT_OK;
   if (n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "too many queries");
-  std::vector<DevMem> tmp;
   void *d_p, *d_n, *d_o;
   int rc;
-  if ((rc = alloc_dev(ctx, tmp, n * 12, &d_p)) || (rc = alloc_dev(ctx, tmp, n * 12, &d_n)) || (rc = alloc_dev(ctx, tmp, n * 12, &d_o))) {
-    free_pool(tmp);
+  if ((rc = scratch_dev(ctx, SC_API_A, n * 12, &d_p)) || (rc = scratch_dev(ctx, SC_API_B, n * 12, &d_n)) || (rc = scratch_dev(ctx, SC_API_C, n * 12, &d_o)))
     return rc;
-  }
-  hipError_t e = hipMemcpyAsync(d_p, P, n * 12, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_n, N, n * 12, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    const int depth = photon_tree_depth(ps.count[which]);
-    LAUNCH_GATHER(k_api_photon_gather, n, depth, photon_dmap(ps, which), (const float*)d_p, (const float*)d_n, (uint32_t)n, radius,
-                  ellipticity, k, depth, (float*)d_o);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(irradiance, d_o, n * 12, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  free_pool(tmp);
-  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(d_p, P, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_n, N, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  const int depth = photon_tree_depth(ps.count[which]);
+  LAUNCH_GATHER(k_api_photon_gather, n, depth, photon_dmap(ps, which), (const float*)d_p, (const float*)d_n, (uint32_t)n, radius,
+                ellipticity, k, depth, (float*)d_o);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(irradiance, d_o, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
@@ -1115,7 +1165,7 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   ensure_gather_hints(ctx, (size_t)P.W * (size_t)P.H);
   G.hints = ctx->d_gather_hints;
   G.n_hint_px = (uint32_t)ctx->gather_hint_px;
-  if (const char* e = std::getenv("RT_GATHER_HINTS")) if (std::atoi(e) == 0) G.hints = nullptr;  // developer knob (tests run both)
+  if (ctx->opt.gather_hints == 0) G.hints = nullptr;  // developer knob (tests run both)
   G.map[0] = photon_dmap(ctx->photons, 0);
   G.map[1] = photon_dmap(ctx->photons, 1);
   G.radius = RP.photon_radius;
@@ -1446,7 +1496,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
   // traversal kernels, and HBM is 288 GB
   double frame_bytes = RP.frame_mem_mb > 0 ? (double)RP.frame_mem_mb * 1048576.0 : 32.0e9;
-  if (const char* e = std::getenv("RT_FRAME_GB")) frame_bytes = std::atof(e) * 1e9;  // developer knob
+  if (ctx->opt.frame_gb > 0) frame_bytes = ctx->opt.frame_gb * 1e9;  // developer knob
   auto budget_for = [&](const double* f) {
     double b = frame_bytes / per_path_bytes(f);
     uint32_t v = (uint32_t)std::min<double>(std::max<double>(b, 65536.0), 201326592.0);
@@ -1600,7 +1650,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     if ((rc = pass(ctx->d_pixels2, (uint32_t)sub.size(), begin, 1, true))) return rc;
     if (overflowed) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow in the sizing pass");
     double margin = 1.5;
-    if (const char* e = std::getenv("RT_TEST_FAN_SCALE")) margin *= std::atof(e);  // tests: force the overflow / split path
+    margin *= ctx->opt.fan_scale;  // tests: force the overflow / split path
     for (int k = 0; k < 7; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
     std::memcpy(ctx->fan_key, fkey, sizeof fkey);
     ctx->fan_valid = true;
@@ -1625,9 +1675,15 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     F.overflow = ctx->d_counts + CNT_OVERFLOW;
   }
 
+  // An asynchronous render reports progress (rt_render_poll, viewport.cpp:583-586): it takes the frame in batches of whole
+  // 32x32 tiles, at least 16 per frame, instead of in the largest pass that fits — GetNumRenderedPixels then advances per
+  // tile batch, as the reference's does per tile.
+  uint32_t progress_chunk = 0xffffffffu;
+  if (track_progress) progress_chunk = std::max<uint32_t>(8u * 1024u, (((n_pix_total + 15u) / 16u) + 1023u) & ~1023u);
+
   if (!adaptive) {
     // fixed sample count: chunks of pixels x chunks of samples
-    uint32_t pix_chunk = std::min<uint32_t>(n_pix_total, budget);
+    uint32_t pix_chunk = std::min<uint32_t>(std::min<uint32_t>(n_pix_total, budget), progress_chunk);
     for (uint32_t p0 = 0; p0 < n_pix_total; p0 += pix_chunk) {
       uint32_t np = std::min(pix_chunk, n_pix_total - p0);
       int ns_max = std::max<int>(1, (int)(budget / np));
@@ -1641,7 +1697,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     // Adaptive: the stop test runs after every sample i >= spp_min (RayTracer.cpp:180-198).  First spp_min+1 samples
     // for every pixel, then small chunks for the pixels still active; k_accumulate applies the test sample by sample
     // and ignores samples past a pixel's stopping point, so the result equals the sequential loop's.
-    uint32_t pix_chunk = std::min<uint32_t>(n_pix_total, budget);
+    uint32_t pix_chunk = std::min<uint32_t>(std::min<uint32_t>(n_pix_total, budget), progress_chunk);
     const int first = std::min(RP.spp_min + 1, RP.spp_max);
     for (uint32_t p0 = 0; p0 < n_pix_total; p0 += pix_chunk) {
       uint32_t np = std::min(pix_chunk, n_pix_total - p0);
@@ -1692,12 +1748,11 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
   }
-  std::vector<DevMem> tmp;
   void *d_rgb = nullptr, *d_rad = nullptr, *d_sc = nullptr;
   int rc = RT_OK;
-  if (fb->rgb8 && (rc = alloc_dev(ctx, tmp, npx * 3, &d_rgb))) { free_pool(tmp); return rc; }
-  if (fb->radiance && (rc = alloc_dev(ctx, tmp, npx * 16, &d_rad))) { free_pool(tmp); return rc; }
-  if (fb->sample_count && (rc = alloc_dev(ctx, tmp, npx * 4, &d_sc))) { free_pool(tmp); return rc; }
+  if (fb->rgb8 && (rc = scratch_dev(ctx, SC_RES_RGB, npx * 3, &d_rgb))) return rc;
+  if (fb->radiance && (rc = scratch_dev(ctx, SC_RES_RAD, npx * 16, &d_rad))) return rc;
+  if (fb->sample_count && (rc = scratch_dev(ctx, SC_RES_CNT, npx * 4, &d_sc))) return rc;
   LAUNCH(k_resolve, npx, W, H, c.srgb, d_accum, (uint8_t*)d_rgb, (float*)d_rad, (int32_t*)d_sc);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && fb->rgb8) e = hipMemcpyAsync(fb->rgb8, d_rgb, npx * 3, hipMemcpyDeviceToHost, ctx->stream);
@@ -1709,9 +1764,29 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
   if (e == hipSuccess && fb->normal && ctx->d_aov_normal) e = hipMemcpyAsync(fb->normal, ctx->d_aov_normal, npx * 12, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && fb->albedo && ctx->d_aov_albedo) e = hipMemcpyAsync(fb->albedo, ctx->d_aov_albedo, npx * 12, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  free_pool(tmp);
   if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
   return RT_OK;
+}
+
+// The filter passes (rt_denoise.h) over an RGBA image in `a`, ping-pong with `b`; returns the buffer that holds the result.
+float4* denoise_passes(rt_context* ctx, int width, int height, float4* a, float4* b, const float4* alb, const float4* nrm) {
+  const size_t n = (size_t)width * height;
+  DenoiseP D;
+  D.W = width; D.H = height;
+  D.inv_sn2 = 1.0f / (RT_DN_SIGMA_N * RT_DN_SIGMA_N);
+  D.inv_sa2 = 1.0f / (RT_DN_SIGMA_A * RT_DN_SIGMA_A);
+  D.has_albedo = alb ? 1 : 0; D.has_normal = nrm ? 1 : 0;
+  float sc = RT_DN_SIGMA_C;
+  Timer t(ctx, RT_K_DENOISE);
+  for (int it = 0; it < RT_DN_ITERS; it++) {
+    D.step = 1 << it;
+    D.inv_sc2 = 1.0f / (sc * sc);
+    LAUNCH(k_dn_atrous, n, D, (const float4*)a, b, alb, nrm);
+    std::swap(a, b);
+    sc = sc * 0.5f;
+  }
+  t.stop((1ull << 32) + n);
+  return a;
 }
 
 int render_blocking(rt_context* ctx, const rt_render_params& RP, rt_framebuffer* fb, bool track) {
@@ -1719,14 +1794,13 @@ int render_blocking(rt_context* ctx, const rt_render_params& RP, rt_framebuffer*
   const rt_camera& c = ctx->camera;
   int W = RP.width > 0 ? RP.width : c.width, H = RP.height > 0 ? RP.height : c.height;
   if (W <= 0 || H <= 0) return fail(ctx, RT_ERR_INVALID, "bad image size");
-  DevMem acc;
-  HIP_TRY(hipMalloc(&acc.p, (size_t)W * H * 8 * sizeof(float)));
-  hipError_t e = hipMemsetAsync(acc.p, 0, (size_t)W * H * 8 * sizeof(float), ctx->stream);
-  int rc = e == hipSuccess ? RT_OK : fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
-  if (!rc) rc = accumulate_internal(ctx, RP, (float*)acc.p, track);
-  if (!rc) rc = resolve_internal(ctx, RP, (const float*)acc.p, fb);
+  void* acc = nullptr;   // the frame's accumulator lives in the context from frame to frame
+  int rc = scratch_dev(ctx, SC_ACCUM, (size_t)W * H * 8 * sizeof(float), &acc);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(acc, 0, (size_t)W * H * 8 * sizeof(float), ctx->stream));
+  rc = accumulate_internal(ctx, RP, (float*)acc, track);
+  if (!rc) rc = resolve_internal(ctx, RP, (const float*)acc, fb);
   (void)hipStreamSynchronize(ctx->stream);
-  acc.release();
   return rc;
 }
 
@@ -1738,7 +1812,7 @@ int rt_render(rt_context* ctx, const rt_render_params* params, rt_framebuffer* f
   if (!ctx) return RT_ERR_INVALID;
   if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
   if (!params || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
-  if (ctx->worker.joinable()) ctx->worker.join();
+  quiesce(ctx);
   return render_blocking(ctx, *params, fb, false);
 }
 
@@ -1782,6 +1856,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, void* 
 
 int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_accum, rt_framebuffer* fb) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
   if (!params || !d_accum || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1790,6 +1865,7 @@ int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_ac
 
 int rt_photons_build(rt_context* ctx, const rt_render_params* params) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
   if (!params) return fail(ctx, RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1799,12 +1875,14 @@ int rt_photons_build(rt_context* ctx, const rt_render_params* params) {
 
 int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
   if (!ctx || !n) return RT_ERR_INVALID;
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   return photon_download(ctx->photons, ctx, which, out, capacity, n);
 }
 
 int rt_photons_set(rt_context* ctx, int which, const rt_photon* photons, int32_t n) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return photon_set(ctx->photons, ctx, which, photons, n);
@@ -1813,6 +1891,7 @@ int rt_photons_set(rt_context* ctx, int which, const rt_photon* photons, int32_t
 int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N, size_t n, float radius, float ellipticity,
                      int k, float* irradiance) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   if (!P || !N || !irradiance) return fail(ctx, RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return photon_gather_api(ctx->photons, ctx, which, P, N, n, radius, ellipticity, k, irradiance);
@@ -1823,44 +1902,27 @@ int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t wid
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_in || !rgb_out || width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
     return fail(ctx, RT_ERR_INVALID, "bad denoise arguments");
-  if (ctx->worker.joinable()) ctx->worker.join();
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t n = (size_t)width * height;
-  std::vector<DevMem> tmp;
-  struct Cleanup { std::vector<DevMem>& t; ~Cleanup() { free_pool(t); } } cleanup{tmp};
-  void *d_rgb, *d_a = nullptr, *d_b = nullptr, *d_alb = nullptr, *d_nrm = nullptr;
+  void *d_rgb, *d_a, *d_b, *d_alb = nullptr, *d_nrm = nullptr;
   int rc;
-  if ((rc = alloc_dev(ctx, tmp, n * 12, &d_rgb)) || (rc = alloc_dev(ctx, tmp, n * 16, &d_a)) || (rc = alloc_dev(ctx, tmp, n * 16, &d_b))) return rc;
-  auto stage = [&](const float* host, void** d_img) -> int {  // host rgb -> device rgba
-    int r = alloc_dev(ctx, tmp, n * 16, d_img);
-    if (r) return r;
+  if ((rc = scratch_dev(ctx, SC_DN_RGB, n * 12, &d_rgb)) || (rc = scratch_dev(ctx, SC_DN_A, n * 16, &d_a)) || (rc = scratch_dev(ctx, SC_DN_B, n * 16, &d_b)))
+    return rc;
+  if (albedo && (rc = scratch_dev(ctx, SC_DN_ALB, n * 16, &d_alb))) return rc;
+  if (normal && (rc = scratch_dev(ctx, SC_DN_NRM, n * 16, &d_nrm))) return rc;
+  // host rgb -> device rgba, one image at a time through the staging buffer (stream order keeps the copies apart)
+  auto stage = [&](const float* host, void* d_img) -> int {
     HIP_TRY(hipMemcpyAsync(d_rgb, host, n * 12, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCH(k_dn_pack, n, (const float*)d_rgb, (float4*)*d_img, (uint32_t)n);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    LAUNCH(k_dn_pack, n, (const float*)d_rgb, (float4*)d_img, (uint32_t)n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // (pageable host memory: the staging buffer is free again)
     return RT_OK;
   };
-  if (albedo && (rc = stage(albedo, &d_alb))) return rc;
-  if (normal && (rc = stage(normal, &d_nrm))) return rc;
-  HIP_TRY(hipMemcpyAsync(d_rgb, rgb_in, n * 12, hipMemcpyHostToDevice, ctx->stream));
-  LAUNCH(k_dn_pack, n, (const float*)d_rgb, (float4*)d_a, (uint32_t)n);
-  DenoiseP D;
-  D.W = width; D.H = height;
-  D.inv_sn2 = 1.0f / (RT_DN_SIGMA_N * RT_DN_SIGMA_N);
-  D.inv_sa2 = 1.0f / (RT_DN_SIGMA_A * RT_DN_SIGMA_A);
-  D.has_albedo = d_alb ? 1 : 0; D.has_normal = d_nrm ? 1 : 0;
-  float sc = RT_DN_SIGMA_C;
-  {
-    Timer t(ctx, RT_K_DENOISE);
-    for (int it = 0; it < RT_DN_ITERS; it++) {
-      D.step = 1 << it;
-      D.inv_sc2 = 1.0f / (sc * sc);
-      LAUNCH(k_dn_atrous, n, D, (const float4*)d_a, (float4*)d_b, (const float4*)d_alb, (const float4*)d_nrm);
-      std::swap(d_a, d_b);
-      sc = sc * 0.5f;
-    }
-    t.stop((1ull << 32) + n);
-  }
-  LAUNCH(k_dn_unpack, n, (const float4*)d_a, (float*)d_rgb, (uint32_t)n);
+  if (albedo && (rc = stage(albedo, d_alb))) return rc;
+  if (normal && (rc = stage(normal, d_nrm))) return rc;
+  if ((rc = stage(rgb_in, d_a))) return rc;
+  float4* res = denoise_passes(ctx, width, height, (float4*)d_a, (float4*)d_b, (const float4*)d_alb, (const float4*)d_nrm);
+  LAUNCH(k_dn_unpack, n, (const float4*)res, (float*)d_rgb, (uint32_t)n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, n * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1873,11 +1935,13 @@ int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t wid
 
 int rt_counters_enable(rt_context* ctx, int enable) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   ctx->counters_on = enable != 0;
   return RT_OK;
 }
 int rt_counters_reset(rt_context* ctx) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof(DCounters)));
   ctx->host_paths = 0;
@@ -1886,6 +1950,7 @@ int rt_counters_reset(rt_context* ctx) {
 int rt_counters_get(rt_context* ctx, rt_counters* out) {
   if (!ctx || !out) return RT_ERR_INVALID;
   static_assert(sizeof(DCounters) == sizeof(rt_counters), "counter layout");
+  quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out, ctx->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost));
@@ -1908,16 +1973,19 @@ int rt_counters_get(rt_context* ctx, rt_counters* out) {
 }
 int rt_profile_enable(rt_context* ctx, int enable) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   ctx->profile_on = enable != 0;
   return RT_OK;
 }
 int rt_profile_reset(rt_context* ctx) {
   if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
   std::memset(&ctx->prof, 0, sizeof ctx->prof);
   return RT_OK;
 }
 int rt_profile_get(rt_context* ctx, rt_profile* out) {
   if (!ctx || !out) return RT_ERR_INVALID;
+  quiesce(ctx);
   *out = ctx->prof;
   return RT_OK;
 }

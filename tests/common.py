@@ -94,15 +94,18 @@ def check_instance_bvh(r, monkeypatch, scene_path_fn):
     assert len(np.unique(c.hit_node)) > 40
     p = params(96, 54, spp=2, jitter=1, bounces=3)
     g, c = r.Render(p), orc.render(p)
-    assert psnr8(g.img, c.img) >= 40.0 and np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean() <= 1e-3
+    assert_stochastic_close(g, c, "sphere field")
     rays = random_rays(4000, seed=21, origin_box=((-60, -40, 0), (60, 380, 80)), target_box=((-50, 0, 0), (50, 360, 60)))
     assert_hits_equal(r.TraceRay(rays, RT_HIT_FRONT_AND_BACK), orc.trace_closest(rays, RT_HIT_FRONT_AND_BACK), "sphere field")
     tmax = np.full(len(rays), 0.8, np.float32)
     assert np.array_equal(r.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax))
-    monkeypatch.setenv("RT_TLAS_MIN", "2")
     for name in ("spheres_room.xml", "cornell_box.xml", "c2_mesh_room.xml"):
         scene = Scene.load(scene_path_fn(name))
-        r.LoadScene(scene)
+        r.set_option("tlas_min", 2)
+        try:
+            r.LoadScene(scene)
+        finally:
+            r.set_option("tlas_min", 24)
         orc = oracle_ffi.OracleScene(scene)
         p = params(160, 90, spp=1, jitter=0, bounces=0)
         g, c = r.Render(p), orc.render(p)
@@ -114,8 +117,32 @@ def check_instance_bvh(r, monkeypatch, scene_path_fn):
         assert np.array_equal(r.TraceShadowRay(rays, tmax), orc.trace_any(rays, tmax)), name
         p = params(96, 54, spp=2, jitter=1, bounces=2)
         g, c = r.Render(p), orc.render(p)
-        assert psnr8(g.img, c.img) >= 40.0, name
+        assert_stochastic_close(g, c, name)
 
+
+TEXTURED = """<xml><scene>
+  <object type="plane" name="floor" material="chk"> <scale value="20"/> </object>
+  <object type="sphere" name="ball" material="glass"> <scale value="3"/> <translate x="-4" z="3"/> </object>
+  <object type="sphere" name="mirror" material="mir"> <scale value="3"/> <translate x="4" z="3"/> </object>
+  <object type="sphere" name="white" material="wht"> <translate x="0" y="-4" z="1"/> </object>
+  <material type="blinn" name="chk">
+    <diffuse texture="checkerboard"> <color1 r="0.9" g="0.2" b="0.2"/>
+      <color2 value="0.8" texture="checkerboard"> <color1 r="0.1" g="0.1" b="0.8"/> <scale value="0.125"/> </color2>
+      <scale value="0.1"/> <rotate angle="30" z="1"/> </diffuse>
+    <specular value="0.2"/> <glossiness value="50"/> <reflection value="0.3"/>
+  </material>
+  <material type="blinn" name="glass"> <diffuse value="0.05"/> <specular value="0.6"/> <glossiness value="40"/>
+    <refraction value="0.85" index="1.4"/> <absorption r="0.05" g="0.01" b="0.02"/> </material>
+  <material type="blinn" name="mir"> <diffuse value="0.1"/> <specular value="0.8"/> <glossiness value="8"/> <reflection value="0.8"/> </material>
+  <material type="microfacet" name="wht"/>
+  <light type="direct"> <intensity value="0.6"/> <direction x="1" y="1" z="-2"/> </light>
+  <light type="point"> <intensity value="60" r="1" g="0.9" b="0.8"/> <position x="0" y="-2" z="9"/> <size value="1.5"/> <attenuation value="1"/> </light>
+  <light type="ambient"> <intensity value="0.2"/> </light>
+  <background r="0.2" g="0.3" b="0.5"/>
+  <environment value="0.7" texture="checkerboard"> <color1 r="0.3" g="0.5" b="0.9"/> <color2 r="0.9" g="0.9" b="0.9"/> <scale value="0.05"/> </environment>
+</scene>
+<camera gamma="sRGB"> <position x="0" y="-18" z="6"/> <target x="0" y="0" z="2"/> <up x="0" y="0" z="1"/> <fov value="40"/>
+  <focaldist value="18"/> <dof value="0.15"/> <width value="96"/> <height value="64"/> </camera></xml>"""
 
 EMPTY_SCENE = """<xml><scene><background r="0.25" g="0.5" b="0.75"/>
 <light type="point"><intensity value="10"/><position x="0" y="0" z="5"/></light></scene>
@@ -217,13 +244,13 @@ def check_random_scene_graphs(r, seeds, n_rays, w, h):
     from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, Scene
     for seed in seeds:
         xml = random_scene_xml(seed, width=w, height=h)
-        for tlas_min in ("1000000", "2"):
-            os.environ["RT_TLAS_MIN"] = tlas_min
+        for tlas_min in (1000000, 2):
+            r.set_option("tlas_min", tlas_min)
             try:
                 scene = Scene.from_string(xml)
                 r.LoadScene(scene)
             finally:
-                del os.environ["RT_TLAS_MIN"]
+                r.set_option("tlas_min", 24)
             orc = oracle_ffi.OracleScene(scene)
             rays = random_rays(n_rays, seed=100 + seed, origin_box=((-20, -30, -8), (20, 20, 16)), target_box=((-8, -8, -6), (8, 8, 8)))
             for side in (RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK):
@@ -237,4 +264,143 @@ def check_random_scene_graphs(r, seeds, n_rays, w, h):
             assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4, f"seed {seed}"
             p = params(w // 2, h // 2, spp=2, jitter=1, bounces=3)
             g, c = r.Render(p), orc.render(p)
-            assert psnr8(g.img, c.img) >= 40.0, f"seed {seed}: PSNR {psnr8(g.img, c.img)}"
+            assert_stochastic_close(g, c, f"random scene graph, seed {seed}", frac=0.999)
+
+
+# ---------------------------------------------------------------------------------------------- stochastic frames
+def stochastic_report(g, c, rel=1e-3):
+    """How close two renders at the same Philox seed / spp are: the share of pixels whose radiance agrees within `rel`
+    (relative to max(|c|, 1)), the largest and mean absolute difference, and the PSNR of the 8-bit images."""
+    a = g.radiance[..., :3].astype(np.float64)
+    b = c.radiance[..., :3].astype(np.float64)
+    d = np.abs(a - b)
+    ok = (d <= rel * np.maximum(np.abs(b), 1.0)).all(axis=-1)
+    return {"frac": float(ok.mean()), "max": float(d.max()), "mean": float(d.mean()), "psnr": float(psnr8(g.img, c.img))}
+
+
+def assert_stochastic_close(g, c, what, frac=0.9995, rel=1e-3, psnr=80.0, mean=1e-6):
+    """Gate for stochastic configurations at equal seed and spp.  The device draws the same Philox numbers as the oracle;
+    what differs is the last ulp of sinf / cosf / powf / expf (device library vs libm) and the order of float sums, so
+    almost every pixel agrees to ~1e-6 and a few differ visibly where an ulp flips a hit / miss or a below-surface
+    decision of one sample.  Required: >= `frac` of the pixels within `rel`, 8-bit PSNR >= `psnr` dB, mean |diff| <= `mean`.
+    (Measured on MI355X, round 2: every pixel within 1e-3, largest difference 7e-4, mean 3e-8 .. 6e-8, PSNR 95 .. 103 dB.)"""
+    s = stochastic_report(g, c, rel)
+    msg = f"{what}: {s}"
+    assert np.array_equal(g.sample_count, c.sample_count), msg
+    assert s["frac"] >= frac, msg
+    assert s["psnr"] >= psnr, msg
+    assert s["mean"] <= mean, msg
+    return s
+
+
+def check_monte_carlo_indirect(r, scene, w, h, spp, strict=None):
+    """SampleIndirectDiffuseCosin (materials.cpp:175-212, call site :309-314) with monteCarloBounces = 2,
+    three specular bounces and the scene's soft shadows (16..128 rays): BASELINE config 3's integrator."""
+    import oracle_ffi
+    r.LoadScene(scene)
+    p = params(w, h, spp=spp, jitter=1, bounces=3, mc=2)
+    g, (c, cnt) = r.Render(p), oracle_ffi.OracleScene(scene).render(p, want_counters=True)
+    assert cnt["rays_secondary"] > 0.5 * cnt["rays_primary"] and cnt["tex_evals"] > 0 and cnt["rays_shadow"] > 16 * cnt["rays_primary"]
+    assert np.array_equal(g.hit_node, c.hit_node)
+    q = params(w, h, spp=spp, jitter=1, bounces=3, mc=0)
+    base = oracle_ffi.OracleScene(scene).render(q)
+    assert np.abs(c.radiance[..., :3] - base.radiance[..., :3]).mean() > 1e-2, "the indirect term contributes nothing"
+    if strict is not None:
+        assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict
+        return None
+    return assert_stochastic_close(g, c, "MC indirect")
+
+
+def check_textured_scene(r, w, h, spp, strict=None):
+    """DOF lens sampling (RayTracer.cpp:152-164), environment mapping (scene.h:373-384), nested + transformed checker
+    textures (texture.cpp:136-140, xmlload.cpp:370-374), a direct light, a soft point light, glossy reflection /
+    refraction with absorption and a microfacet (white stub) material, in one frame."""
+    import oracle_ffi
+    from raytracer_amd import Scene
+    scene = Scene.from_string(TEXTURED)
+    assert scene.desc.n_texmaps == 3
+    r.LoadScene(scene)
+    p = params(w, h, spp=spp, jitter=1, bounces=3)
+    g, (c, cnt) = r.Render(p), oracle_ffi.OracleScene(scene).render(p, want_counters=True)
+    assert cnt["tex_evals"] > 0 and cnt["rays_secondary"] > 0
+    assert np.array_equal(g.hit_node, c.hit_node)
+    if strict is not None:
+        assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict
+        return None
+    return assert_stochastic_close(g, c, "textured scene")
+
+
+def check_adaptive_sampling(r, scene, w, h, spp_min, spp_max, threshold, bounces=2, strict=None, equal_frac=1.0):
+    """RayTracer.cpp:136-204: the Student-t stop test after every sample >= spp_min (SURVEY Q1 / Q2 positions); the
+    per-pixel sample counts are the observable.  `equal_frac`: share of pixels whose count must equal the oracle's (a
+    pixel whose half-width sits within an ulp of the threshold may stop one sample apart on the device)."""
+    import oracle_ffi
+    r.LoadScene(scene)
+    p = params(w, h, jitter=1, bounces=bounces)
+    p.spp_min, p.spp_max = spp_min, spp_max
+    p.adaptive_threshold = threshold
+    g, c = r.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert c.sample_count.min() == spp_min + 1 and c.sample_count.max() == spp_max and len(np.unique(c.sample_count)) > 3
+    same = g.sample_count == c.sample_count
+    assert same.mean() >= equal_frac, f"sample counts equal for {same.mean():.5f} of the pixels"
+    assert np.abs(g.sample_count - c.sample_count).max() <= (0 if equal_frac >= 1.0 else spp_max)
+    d = np.abs(g.radiance[..., :3] - c.radiance[..., :3])
+    if strict is not None:
+        assert d.max() <= strict
+    else:
+        assert d[same].mean() <= 2e-5 and (d[same] <= 1e-3).mean() >= 0.999
+    return float(same.mean())
+
+
+def check_async_render(r, scene, w, h, spp):
+    """BeginRender ("returns immediately", renderer.h:229) + polling GetNumRenderedPixels / IsRenderDone as the viewport
+    does (viewport.cpp:583-586) + StopRender (renderer.h:230) gives the frame Render gives."""
+    import time
+    r.LoadScene(scene)
+    p = params(w, h, spp=spp, jitter=1, bounces=2)
+    ref = r.Render(p)
+    r.BeginRender(p)
+    seen = [r.GetNumRenderedPixels()]
+    t0 = time.time()
+    while not r.IsRenderDone() and time.time() - t0 < 60.0:
+        seen.append(r.GetNumRenderedPixels())
+        time.sleep(0.0005)
+    assert r.IsRenderDone()
+    img = r.StopRender()
+    seen.append(r.GetNumRenderedPixels())
+    assert seen[-1] == w * h and all(b >= a for a, b in zip(seen, seen[1:])) and min(seen) >= 0
+    assert np.array_equal(img.hit_node, ref.hit_node) and np.array_equal(img.sample_count, ref.sample_count)
+    # (float atomics into a path's radiance slot are unordered: equal to the order of the sums)
+    assert np.allclose(img.radiance, ref.radiance, rtol=1e-5, atol=1e-6)
+    assert (img.img == ref.img).mean() > 0.999
+    # a second BeginRender while nothing runs, then a blocking Render right behind it (joins the worker first)
+    r.BeginRender(p)
+    again = r.Render(p)
+    assert np.allclose(again.radiance, ref.radiance, rtol=1e-5, atol=1e-6)
+    return seen
+
+
+def check_stress_scene(r, scene, w, h, n_rays):
+    """BASELINE config 5's workload shape (rth_scene_generate_stress: icospheres over a displaced ground in ONE mesh,
+    two sphere lights): node + face ids bit-exact at the pixel centre, batched closest / any-hit parity, and a
+    stochastic frame with soft shadows and three bounces."""
+    import oracle_ffi
+    from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p = params(w, h, spp=1, jitter=0, bounces=0)
+    g, c = r.Render(p), orc.render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
+    assert (c.hit_face >= 0).mean() > 0.2 and len(np.unique(c.hit_face)) > 1000
+    assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4
+    lo = np.array(scene.desc.meshes[0].bound_min[:], np.float32)
+    hi = np.array(scene.desc.meshes[0].bound_max[:], np.float32)
+    pad = 0.1 * (hi - lo)
+    rays = random_rays(n_rays, seed=77, origin_box=(tuple(lo - pad), tuple(hi + pad)), target_box=(tuple(lo), tuple(hi)))
+    for side in (RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK):
+        assert_hits_equal(r.TraceRay(rays, side), orc.trace_closest(rays, side), f"stress scene side {side}")
+    tmax = np.full(len(rays), 0.6, np.float32)
+    tmax[::3] = np.finfo(np.float32).max
+    occ = orc.trace_any(rays, tmax)
+    assert np.array_equal(r.TraceShadowRay(rays, tmax), occ) and 0.05 < occ.mean() < 0.95
+    return g, c

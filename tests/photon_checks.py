@@ -115,6 +115,7 @@ def check_photon_maps_match_sequential_emitter(r, scene, n_photons=2000, emit_li
         if exact:
             assert ok.all(), f"map {which}: {np.count_nonzero(~ok)} photons differ in position"
         else:
+            print(f"photon map {which}: {ok.mean():.5f} of the photons identical")
             assert ok.mean() >= 0.98, f"map {which}: only {ok.mean():.3f} of the photons match"
         assert np.abs(g["dir"][ok] - c["dir"][ok]).max() <= 1e-3
         # (powers can be negative: mult = ks * dot(newDir, N) is not clamped, materials.cpp:372)
@@ -173,12 +174,12 @@ def check_gather_hints(r, scene, n_photons=3000, w=64, h=36, spp=2, tol=2e-6):
     cold, n_cold = render(p)
     warm, n_warm = render(p)
     other, _ = render(p2)
-    os.environ["RT_GATHER_HINTS"] = "0"
+    r.set_option("gather_hints", 0)
     try:
         off, n_off = render(p)
         other_off, _ = render(p2)
     finally:
-        del os.environ["RT_GATHER_HINTS"]
+        r.set_option("gather_hints", 1)
     assert n_cold > 0
     same(warm, cold, "warm hints changed the frame")
     same(off, cold, "hints changed the frame")

@@ -10,34 +10,9 @@ import oracle_ffi
 import os
 
 import common as common_checks
-from common import assert_hits_equal, params, psnr8, random_rays, rel_colour_diff
+from common import TEXTURED, assert_hits_equal, params, psnr8, random_rays, rel_colour_diff
 from conftest import ROOT, scene_path
 from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK, Scene
-
-TEXTURED = """<xml><scene>
-  <object type="plane" name="floor" material="chk"> <scale value="20"/> </object>
-  <object type="sphere" name="ball" material="glass"> <scale value="3"/> <translate x="-4" z="3"/> </object>
-  <object type="sphere" name="mirror" material="mir"> <scale value="3"/> <translate x="4" z="3"/> </object>
-  <object type="sphere" name="white" material="wht"> <translate x="0" y="-4" z="1"/> </object>
-  <material type="blinn" name="chk">
-    <diffuse texture="checkerboard"> <color1 r="0.9" g="0.2" b="0.2"/>
-      <color2 value="0.8" texture="checkerboard"> <color1 r="0.1" g="0.1" b="0.8"/> <scale value="0.125"/> </color2>
-      <scale value="0.1"/> <rotate angle="30" z="1"/> </diffuse>
-    <specular value="0.2"/> <glossiness value="50"/> <reflection value="0.3"/>
-  </material>
-  <material type="blinn" name="glass"> <diffuse value="0.05"/> <specular value="0.6"/> <glossiness value="40"/>
-    <refraction value="0.85" index="1.4"/> <absorption r="0.05" g="0.01" b="0.02"/> </material>
-  <material type="blinn" name="mir"> <diffuse value="0.1"/> <specular value="0.8"/> <glossiness value="8"/> <reflection value="0.8"/> </material>
-  <material type="microfacet" name="wht"/>
-  <light type="direct"> <intensity value="0.6"/> <direction x="1" y="1" z="-2"/> </light>
-  <light type="point"> <intensity value="60" r="1" g="0.9" b="0.8"/> <position x="0" y="-2" z="9"/> <size value="1.5"/> <attenuation value="1"/> </light>
-  <light type="ambient"> <intensity value="0.2"/> </light>
-  <background r="0.2" g="0.3" b="0.5"/>
-  <environment value="0.7" texture="checkerboard"> <color1 r="0.3" g="0.5" b="0.9"/> <color2 r="0.9" g="0.9" b="0.9"/> <scale value="0.05"/> </environment>
-</scene>
-<camera gamma="sRGB"> <position x="0" y="-18" z="6"/> <target x="0" y="0" z="2"/> <up x="0" y="0" z="1"/> <fov value="40"/>
-  <focaldist value="18"/> <dof value="0.15"/> <width value="96"/> <height value="64"/> </camera></xml>"""
-
 
 @pytest.fixture(scope="module")
 def emu():
@@ -77,35 +52,59 @@ def test_recursion_unrolled_into_queues(emu, name, spp, bounces):
 
 
 def test_textures_dof_environment_direct_light_white_material(emu):
-    scene = Scene.from_string(TEXTURED)
-    assert scene.desc.n_texmaps == 3
-    emu.LoadScene(scene)
-    p = params(96, 64, spp=3, jitter=1, bounces=3)
-    g, (c, cnt) = emu.Render(p), oracle_ffi.OracleScene(scene).render(p, want_counters=True)
-    assert cnt["tex_evals"] > 0 and cnt["rays_secondary"] > 0
-    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
-    assert np.array_equal(g.hit_node, c.hit_node)
+    common_checks.check_textured_scene(emu, 96, 64, spp=3, strict=5e-5)
 
 
 def test_monte_carlo_indirect(emu):
-    scene = Scene.from_string(TEXTURED)
-    emu.LoadScene(scene)
-    p = params(64, 48, spp=2, jitter=1, bounces=2, mc=2)
-    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
-    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
+    common_checks.check_monte_carlo_indirect(emu, Scene.from_string(TEXTURED), 64, 48, spp=2, strict=5e-5)
+
+
+def test_monte_carlo_indirect_config3_scene(emu):
+    """BASELINE config 3's scene and integrator (checker floor, brick wall, cloud environment, mc = 2, soft shadows)."""
+    common_checks.check_monte_carlo_indirect(emu, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 40, 24, spp=2,
+                                             strict=5e-5)
 
 
 def test_adaptive_sampling_matches_sequential_loop(emu):
     """RayTracer.cpp:136-204: the stop test after every sample >= spp_min; Q1/Q2 positions."""
+    common_checks.check_adaptive_sampling(emu, Scene.load(scene_path("cornell_box.xml")), 48, 27, 4, 24, 0.02, strict=2e-5)
+
+
+def test_async_render_equals_blocking_render(emu):
+    seen = common_checks.check_async_render(emu, Scene.load(scene_path("cornell_box.xml")), 160, 120, spp=2)
+    assert len(set(seen)) >= 3, f"rt_render_poll never showed a partial frame: {sorted(set(seen))}"
+
+
+def test_stress_scene_scaled(emu):
+    """BASELINE config 5's generator at ~1/250 of its size."""
+    scene = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
+    assert 45000 < scene.n_triangles() < 60000
+    common_checks.check_stress_scene(emu, scene, 160, 90, n_rays=1500)
+
+
+def test_steady_state_calls_do_not_allocate(emu):
+    """Entry points keep their device buffers in the context (grow-only): repeating a call allocates nothing."""
     scene = Scene.load(scene_path("cornell_box.xml"))
     emu.LoadScene(scene)
-    p = params(48, 27, jitter=1, bounces=2)
-    p.spp_min, p.spp_max = 4, 24
-    p.adaptive_threshold = 0.02
-    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
-    assert np.array_equal(g.sample_count, c.sample_count)
-    assert c.sample_count.min() == 5 and c.sample_count.max() == 24 and len(np.unique(c.sample_count)) > 3
-    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 2e-5
+    p = params(96, 54, spp=2, jitter=1, bounces=2)
+    rays = random_rays(500, seed=3)
+    tmax = np.full(len(rays), 1.0, np.float32)
+    acc = np.zeros(96 * 54 * 8, np.float32)
+
+    def calls():
+        emu.Render(p)
+        emu.render_accumulate(p, acc.ctypes.data)
+        emu.resolve(p, acc.ctypes.data)
+        emu.TraceRay(rays)
+        emu.TraceShadowRay(rays, tmax)
+        emu.Denoise(np.zeros((54, 96, 3), np.float32))
+
+    calls()
+    before = emu.alloc_count()
+    assert before > 0
+    for _ in range(3):
+        calls()
+    assert emu.alloc_count() == before
 
 
 def test_tile_and_sample_partitions_reproduce_the_frame(emu):
@@ -173,8 +172,8 @@ def test_error_paths(emu):
 def test_undersized_queues_split_the_pass_and_still_match(monkeypatch):
     """Queue capacities come from a measured sizing pass; a pass that overflows anyway leaves the accumulator alone and
     is re-run in halves.  Forced here by shrinking the measured fan-out 20x: the frame must still equal the oracle's."""
-    monkeypatch.setenv("RT_TEST_FAN_SCALE", "0.05")
     r = emu_ffi.EmuRenderer()
+    r.set_option("fan_scale", 0.05)
     scene = Scene.load(scene_path("cornell_box.xml"))
     r.LoadScene(scene)
     p = params(128, 128, spp=4, jitter=1, bounces=2)
@@ -233,4 +232,5 @@ def test_every_bundled_reference_scene_renders_like_the_oracle(emu):
         p = params(32, 18, spp=2, jitter=1, bounces=2)
         p.shadow_min, p.shadow_max = 4, 8
         g, c = emu.Render(p), orc.render(p)
-        assert psnr8(g.img, c.img) >= 40.0, f"{f}: PSNR {psnr8(g.img, c.img):.1f}"
+        assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 1e-4, f
+        assert psnr8(g.img, c.img) >= 60.0, f"{f}: PSNR {psnr8(g.img, c.img):.1f}"

@@ -1,0 +1,127 @@
+"""GPU parity of the BASELINE configurations the round-1 suite did not run on hardware, through the C-ABI against the CPU
+oracle: the Monte-Carlo indirect path (C3), adaptive sampling (C4's single-GPU mode), depth of field / environment /
+nested textures, the stress-scene generator (C5, scaled and full size) and the asynchronous Begin / poll / Stop API."""
+import os
+
+import numpy as np
+import pytest
+
+import common as cc
+from common import params
+from conftest import ROOT, scene_path
+from raytracer_amd import RT_HIT_FRONT, Scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_monte_carlo_indirect(gpu_renderer):
+    """BASELINE config 3: textured Cornell box, SampleIndirectDiffuseCosin x 2 bounces + 3 specular bounces + soft shadows
+    (materials.cpp:175-212, :309-314), radiance compared at the same Philox seed."""
+    s = cc.check_monte_carlo_indirect(gpu_renderer, Scene.load(os.path.join(ROOT, "scenes", "c3_cornell_textured.xml")), 320, 180, spp=4)
+    print("c3 mc:", s)
+
+
+def test_monte_carlo_on_textured_scene(gpu_renderer):
+    s = cc.check_monte_carlo_indirect(gpu_renderer, Scene.from_string(cc.TEXTURED), 192, 128, spp=4)
+    print("textured mc:", s)
+
+
+def test_textures_dof_environment_direct_light(gpu_renderer):
+    s = cc.check_textured_scene(gpu_renderer, 384, 256, spp=4)
+    print("textured:", s)
+
+
+def test_adaptive_sampling_4_24(gpu_renderer):
+    f = cc.check_adaptive_sampling(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), 240, 135, 4, 24, 0.02, equal_frac=0.9995)
+    print("adaptive 4..24: equal sample counts for", f)
+
+
+def test_adaptive_sampling_reference_32_128(gpu_renderer):
+    """The reference's own constants: minSamples 32, maxSamples 128, threshold 0.01 (raytracer.h:20-21, RayTracer.cpp:191)."""
+    f = cc.check_adaptive_sampling(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), 96, 54, 32, 128, 0.01, equal_frac=0.9995)
+    print("adaptive 32..128: equal sample counts for", f)
+
+
+def test_async_render_equals_blocking_render(gpu_renderer):
+    seen = cc.check_async_render(gpu_renderer, Scene.load(scene_path("c2_mesh_room.xml")), 960, 540, spp=8)
+    assert len(set(seen)) >= 3, f"rt_render_poll never showed a partial frame: {sorted(set(seen))}"
+
+
+def test_c5_stress_scene_scaled(gpu_renderer):
+    """BASELINE config 5's generator at 1/55 of its size (227k triangles in one BVH): ids bit-exact, batched parity, and a
+    stochastic frame with the two sphere lights' soft shadows."""
+    import oracle_ffi
+    scene = Scene.stress(seed=7, n_instances=96, subdiv=3, ground_res=230, width=480, height=270)
+    assert 200000 < scene.n_triangles() < 300000
+    cc.check_stress_scene(gpu_renderer, scene, 480, 270, n_rays=20000)
+    p = params(240, 135, spp=2, jitter=1, bounces=3)
+    g, c = gpu_renderer.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    print("c5 scaled:", cc.assert_stochastic_close(g, c, "stress scene"))
+
+
+def test_c5_stress_scene_full_size(gpu_renderer):
+    """BASELINE config 5 at full size (12.6 M triangles in one BVH, 4K): properties that need no full CPU render — no
+    queue overflow / walk abort (the call succeeds), every pixel sampled, the frame's two-phase kernels and the batched
+    one-phase walk agree on node AND face ids for the same camera rays, and the oracle agrees on a tile subset."""
+    import oracle_ffi
+    scene = Scene.stress(seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160)
+    assert scene.n_triangles() > 12_000_000
+    gpu_renderer.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p = params(3840, 2160, spp=1, jitter=0, bounces=0, light_scale=0.0)   # (one shadow ray per light: the oracle walks 12.6 M triangles too)
+    g = gpu_renderer.Render(p)
+    assert (g.sample_count == 1).all()
+    assert (g.hit_face >= 0).mean() > 0.2
+    # the same camera rays through the batched entry point (pixel centres of every 37th row, every 11th column)
+    ys, xs = np.arange(5, 2160, 37), np.arange(3, 3840, 11)
+    rays = np.zeros(len(ys) * len(xs), dtype=cc.rays_from_arrays(np.zeros((1, 3)), np.zeros((1, 3))).dtype)
+    k = 0
+    for y in ys[:: max(1, len(ys) // 12)]:
+        for x in xs:
+            o, d = orc.primary_ray(p, int(x), int(y), 0)
+            rays["p"][k], rays["dir"][k] = o, d
+            k += 1
+    rays = rays[:k]
+    yy = np.repeat(ys[:: max(1, len(ys) // 12)], len(xs))[:k]
+    xx = np.tile(xs, len(ys))[:k]
+    hits = gpu_renderer.TraceRay(rays, RT_HIT_FRONT)
+    assert np.array_equal(hits["node"], g.hit_node[yy, xx]) and np.array_equal(hits["face"], g.hit_face[yy, xx])
+    # the oracle on every 509th 32x32 tile (16 tiles): ids bit-exact, colour within 1e-4
+    q = params(3840, 2160, spp=1, jitter=0, bounces=0, light_scale=0.0)
+    q.tile_begin, q.tile_stride = 0, 509
+    c = orc.render(q)
+    covered = c.sample_count > 0
+    assert covered.sum() >= 16 * 1024 * 0.9
+    assert np.array_equal(g.hit_node[covered], c.hit_node[covered]) and np.array_equal(g.hit_face[covered], c.hit_face[covered])
+    assert cc.rel_colour_diff(g.radiance[covered], c.radiance[covered]) <= 1e-4
+    # shadow rays: batched any-hit against the oracle on the same rays
+    tmax = np.full(len(rays), np.finfo(np.float32).max, np.float32)
+    sub = slice(0, 1500)
+    assert np.array_equal(gpu_renderer.TraceShadowRay(rays[sub], tmax[sub]), orc.trace_any(rays[sub], tmax[sub]))
+
+
+def test_steady_state_calls_do_not_allocate(gpu_renderer):
+    """no hipMalloc / hipFree in a steady-state rt_render / rt_render_accumulate / rt_resolve /
+    rt_trace_* / rt_denoise (the buffers live in the context, grow-only)."""
+    import torch
+    scene = Scene.load(scene_path("c2_mesh_room.xml"))
+    gpu_renderer.LoadScene(scene)
+    p = params(480, 270, spp=4, jitter=1, bounces=3)
+    rays = cc.random_rays(5000, seed=3)
+    tmax = np.full(len(rays), 1.0, np.float32)
+    acc = torch.zeros(480 * 270 * 8, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+
+    def calls():
+        gpu_renderer.Render(p)
+        gpu_renderer.render_accumulate(p, acc.data_ptr())
+        gpu_renderer.resolve(p, acc.data_ptr())
+        gpu_renderer.TraceRay(rays)
+        gpu_renderer.TraceShadowRay(rays, tmax)
+        gpu_renderer.Denoise(np.zeros((270, 480, 3), np.float32))
+
+    calls()
+    before = gpu_renderer.alloc_count()
+    for _ in range(3):
+        calls()
+    assert gpu_renderer.alloc_count() == before
