@@ -300,6 +300,16 @@ int rt_photon_gather(rt_context* ctx, int which, const float* P, const float* N,
 int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t width, int32_t height,
                const float* albedo, const float* normal);
 
+/* rt_denoise without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate device
+ * memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same filter and kernels as
+ * rt_denoise, but d_rgb_in / d_rgb_out / d_albedo / d_normal are DEVICE pointers (W*H*3 floats each, guides may be NULL)
+ * and the filter's working images live in a fixed 64 MiB device array of the library (one copy per GPU, held until the
+ * process ends) instead of allocated buffers.  Limit: width * height <= 1048576 pixels (RT_ERR_UNSUPPORTED beyond it).
+ * Calls no hipMalloc / hipFree.  Blocks until the result is in d_rgb_out.  Every call on one GPU shares that GPU's
+ * array: calls that overlap on one GPU (from several contexts or threads) race and must be serialised by the caller. */
+int rt_denoise_noalloc(rt_context* ctx, const float* d_rgb_in, float* d_rgb_out, int32_t width, int32_t height,
+                       const float* d_albedo, const float* d_normal);
+
 int rt_counters_enable(rt_context* ctx, int enable); /* counted builds of the kernels; off by default */
 int rt_counters_reset(rt_context* ctx);
 int rt_counters_get(rt_context* ctx, rt_counters* out);

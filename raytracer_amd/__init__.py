@@ -250,6 +250,11 @@ class Renderer:
                                          n.ctypes.data if n is not None else None), "rt_denoise")
         return out
 
+    def denoise_noalloc(self, d_rgb_in, d_rgb_out, width, height, d_albedo=0, d_normal=0):
+        """rt_denoise_noalloc: device pointers (ints), no allocation; see include/rtcore.h."""
+        self._check(self._lib.rt_denoise_noalloc(self._ctx, C.c_void_p(d_rgb_in), C.c_void_p(d_rgb_out), width, height,
+                                                 C.c_void_p(d_albedo or None), C.c_void_p(d_normal or None)), "rt_denoise_noalloc")
+
     # -- multi-GPU / measurement helpers ---------------------------------------------------
     def render_accumulate(self, params, d_accum_ptr):
         self._check(self._lib.rt_render_accumulate(self._ctx, C.byref(params), C.c_void_p(d_accum_ptr)),

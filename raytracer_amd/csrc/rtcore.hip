@@ -79,6 +79,19 @@ T* dptr(const DevMem& m) { return (T*)m.p; }
 
 }  // namespace
 
+// ---- rt_denoise_noalloc: the filter's working images in a fixed device array instead of allocated buffers.
+// RT_NOALLOC_MAX_PIXELS pixels x 4 RGBA float images (ping, pong, albedo guide, normal guide) = 64 MiB, held by every GPU the
+// library runs on until the process ends.  In host code the array's NAME is only a stand-in for the symbol: its device
+// address on a given GPU comes from hipGetSymbolAddress (rt_context_create, with that device current) and is what the
+// kernels and copies are given.
+#define RT_NOALLOC_MAX_PIXELS (1u << 20)
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_PIXELS * 4u * 16u)
+#ifndef RT_EMU
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+#else
+alignas(256) static unsigned char scratch[RT_NOALLOC_BYTES];
+#endif
+
 // Developer knobs (tests force both sides of a threshold with them).  Read from the environment ONCE, when the context is
 // created, and settable per context through rt_set_option; nothing on the render path calls getenv.
 struct Options {
@@ -98,7 +111,8 @@ struct rt_context {
   hipStream_t stream = nullptr;
   std::string err;
   Options opt;
-  DevMem scratch[SC_COUNT];
+  unsigned char* noalloc_ptr = nullptr;   // this GPU's copy of the file-scope `scratch` array (hipGetSymbolAddress)
+  DevMem bufs[SC_COUNT];
   uint64_t n_allocs = 0;   // hipMalloc calls made on behalf of this context (rt_debug_alloc_count)
   int max_blocks = 2048, max_blocks_trace = 1024;
   int n_cus = 256;
@@ -174,8 +188,8 @@ int alloc_dev(rt_context* ctx, std::vector<DevMem>& pool, size_t bytes, void** o
 }
 // The context's grow-only buffer `slot`, at least `bytes` large.  (Callers have synchronised the stream before a buffer
 // can be replaced: every entry point that uses one ends with a stream synchronisation.)
-int scratch_dev(rt_context* ctx, int slot, size_t bytes, void** out) {
-  DevMem& m = ctx->scratch[slot];
+int grow_dev(rt_context* ctx, int slot, size_t bytes, void** out) {
+  DevMem& m = ctx->bufs[slot];
   if (bytes == 0) bytes = 16;
   if (!m.p || m.bytes < bytes) {
     m.release();
@@ -431,6 +445,20 @@ int rt_context_create(int device_id, rt_context** out) {
   if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
   ctx->d_counters = (DCounters*)p;
   (void)hipMemset(p, 0, sizeof(DCounters));
+  {  // this device's address of the no-allocation entry point's working array (the device is current: hipSetDevice above)
+#ifndef RT_EMU
+    void* sp = nullptr;
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
+      (void)hipFree(p);
+      (void)hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return RT_ERR_DEVICE;
+    }
+    ctx->noalloc_ptr = (unsigned char*)sp;
+#else
+    ctx->noalloc_ptr = scratch;
+#endif
+  }
   // developer knobs: the environment is read here and nowhere else
   auto env = [](const char* name, double& v) { if (const char* e = std::getenv(name)) v = std::atof(e); };
   env("RT_TLAS_MIN", ctx->opt.tlas_min);
@@ -469,7 +497,7 @@ void rt_context_destroy(rt_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   free_pool(ctx->scene_mem);
   free_pool(ctx->frame_mem);
-  for (auto& m : ctx->scratch) m.release();
+  for (auto& m : ctx->bufs) m.release();
   photon_state_free(ctx->photons);
   if (ctx->d_gather_hints) (void)hipFree(ctx->d_gather_hints);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -745,7 +773,7 @@ int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side
   HIP_TRY(hipSetDevice(ctx->device));
   void *d_r, *d_h;
   int rc;
-  if ((rc = scratch_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = scratch_dev(ctx, SC_API_B, n * sizeof(rt_hit), &d_h))) return rc;
+  if ((rc = grow_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = grow_dev(ctx, SC_API_B, n * sizeof(rt_hit), &d_h))) return rc;
   HIP_TRY(hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream));
   LAUNCH_T(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
   HIP_TRY(hipGetLastError());
@@ -763,8 +791,8 @@ int rt_trace_any(rt_context* ctx, const rt_ray* rays, const float* t_max, size_t
   HIP_TRY(hipSetDevice(ctx->device));
   void *d_r, *d_t = nullptr, *d_o;
   int rc;
-  if ((rc = scratch_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = scratch_dev(ctx, SC_API_B, n, &d_o))) return rc;
-  if (t_max && (rc = scratch_dev(ctx, SC_API_C, n * sizeof(float), &d_t))) return rc;
+  if ((rc = grow_dev(ctx, SC_API_A, n * sizeof(rt_ray), &d_r)) || (rc = grow_dev(ctx, SC_API_B, n, &d_o))) return rc;
+  if (t_max && (rc = grow_dev(ctx, SC_API_C, n * sizeof(float), &d_t))) return rc;
   HIP_TRY(hipMemcpyAsync(d_r, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream));
   if (t_max) HIP_TRY(hipMemcpyAsync(d_t, t_max, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   LAUNCH_T(k_api_any, n, ctx->ds, (const float*)d_r, (const float*)d_t, (uint32_t)n, (uint8_t*)d_o);
@@ -799,7 +827,7 @@ struct Timer {
   int kind;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  Timer(rt_context* c, int k) : ctx(c), kind(k), on(c->profile_on) {
+  Timer(rt_context* c, int k, bool allowed = true) : ctx(c), kind(k), on(c->profile_on && allowed) {
     if (!on) return;
     auto take = [&]() {
       hipEvent_t e;
@@ -1129,7 +1157,7 @@ int photon_gather_api(PhotonState& ps, rt_context* ctx, int which, const float* 
   if (n > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "too many queries");
   void *d_p, *d_n, *d_o;
   int rc;
-  if ((rc = scratch_dev(ctx, SC_API_A, n * 12, &d_p)) || (rc = scratch_dev(ctx, SC_API_B, n * 12, &d_n)) || (rc = scratch_dev(ctx, SC_API_C, n * 12, &d_o)))
+  if ((rc = grow_dev(ctx, SC_API_A, n * 12, &d_p)) || (rc = grow_dev(ctx, SC_API_B, n * 12, &d_n)) || (rc = grow_dev(ctx, SC_API_C, n * 12, &d_o)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_p, P, n * 12, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d_n, N, n * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -1750,9 +1778,9 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
   }
   void *d_rgb = nullptr, *d_rad = nullptr, *d_sc = nullptr;
   int rc = RT_OK;
-  if (fb->rgb8 && (rc = scratch_dev(ctx, SC_RES_RGB, npx * 3, &d_rgb))) return rc;
-  if (fb->radiance && (rc = scratch_dev(ctx, SC_RES_RAD, npx * 16, &d_rad))) return rc;
-  if (fb->sample_count && (rc = scratch_dev(ctx, SC_RES_CNT, npx * 4, &d_sc))) return rc;
+  if (fb->rgb8 && (rc = grow_dev(ctx, SC_RES_RGB, npx * 3, &d_rgb))) return rc;
+  if (fb->radiance && (rc = grow_dev(ctx, SC_RES_RAD, npx * 16, &d_rad))) return rc;
+  if (fb->sample_count && (rc = grow_dev(ctx, SC_RES_CNT, npx * 4, &d_sc))) return rc;
   LAUNCH(k_resolve, npx, W, H, c.srgb, d_accum, (uint8_t*)d_rgb, (float*)d_rad, (int32_t*)d_sc);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && fb->rgb8) e = hipMemcpyAsync(fb->rgb8, d_rgb, npx * 3, hipMemcpyDeviceToHost, ctx->stream);
@@ -1769,7 +1797,7 @@ int resolve_internal(rt_context* ctx, const rt_render_params& RP, const float* d
 }
 
 // The filter passes (rt_denoise.h) over an RGBA image in `a`, ping-pong with `b`; returns the buffer that holds the result.
-float4* denoise_passes(rt_context* ctx, int width, int height, float4* a, float4* b, const float4* alb, const float4* nrm) {
+float4* denoise_passes(rt_context* ctx, int width, int height, float4* a, float4* b, const float4* alb, const float4* nrm, bool timed = true) {
   const size_t n = (size_t)width * height;
   DenoiseP D;
   D.W = width; D.H = height;
@@ -1777,7 +1805,7 @@ float4* denoise_passes(rt_context* ctx, int width, int height, float4* a, float4
   D.inv_sa2 = 1.0f / (RT_DN_SIGMA_A * RT_DN_SIGMA_A);
   D.has_albedo = alb ? 1 : 0; D.has_normal = nrm ? 1 : 0;
   float sc = RT_DN_SIGMA_C;
-  Timer t(ctx, RT_K_DENOISE);
+  Timer t(ctx, RT_K_DENOISE, timed);   // (profiling creates events: never on the no-allocation path)
   for (int it = 0; it < RT_DN_ITERS; it++) {
     D.step = 1 << it;
     D.inv_sc2 = 1.0f / (sc * sc);
@@ -1795,7 +1823,7 @@ int render_blocking(rt_context* ctx, const rt_render_params& RP, rt_framebuffer*
   int W = RP.width > 0 ? RP.width : c.width, H = RP.height > 0 ? RP.height : c.height;
   if (W <= 0 || H <= 0) return fail(ctx, RT_ERR_INVALID, "bad image size");
   void* acc = nullptr;   // the frame's accumulator lives in the context from frame to frame
-  int rc = scratch_dev(ctx, SC_ACCUM, (size_t)W * H * 8 * sizeof(float), &acc);
+  int rc = grow_dev(ctx, SC_ACCUM, (size_t)W * H * 8 * sizeof(float), &acc);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(acc, 0, (size_t)W * H * 8 * sizeof(float), ctx->stream));
   rc = accumulate_internal(ctx, RP, (float*)acc, track);
@@ -1907,10 +1935,10 @@ int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t wid
   const size_t n = (size_t)width * height;
   void *d_rgb, *d_a, *d_b, *d_alb = nullptr, *d_nrm = nullptr;
   int rc;
-  if ((rc = scratch_dev(ctx, SC_DN_RGB, n * 12, &d_rgb)) || (rc = scratch_dev(ctx, SC_DN_A, n * 16, &d_a)) || (rc = scratch_dev(ctx, SC_DN_B, n * 16, &d_b)))
+  if ((rc = grow_dev(ctx, SC_DN_RGB, n * 12, &d_rgb)) || (rc = grow_dev(ctx, SC_DN_A, n * 16, &d_a)) || (rc = grow_dev(ctx, SC_DN_B, n * 16, &d_b)))
     return rc;
-  if (albedo && (rc = scratch_dev(ctx, SC_DN_ALB, n * 16, &d_alb))) return rc;
-  if (normal && (rc = scratch_dev(ctx, SC_DN_NRM, n * 16, &d_nrm))) return rc;
+  if (albedo && (rc = grow_dev(ctx, SC_DN_ALB, n * 16, &d_alb))) return rc;
+  if (normal && (rc = grow_dev(ctx, SC_DN_NRM, n * 16, &d_nrm))) return rc;
   // host rgb -> device rgba, one image at a time through the staging buffer (stream order keeps the copies apart)
   auto stage = [&](const float* host, void* d_img) -> int {
     HIP_TRY(hipMemcpyAsync(d_rgb, host, n * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -1930,6 +1958,32 @@ int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t wid
     std::vector<uint32_t> none;
     collect_profile(ctx, none);
   }
+  return RT_OK;
+}
+
+// rt_denoise for callers that cannot allocate: device images in, device image out, the working images in this GPU's copy
+// of the file-scope `scratch` array.  No hipMalloc / hipFree / allocating call on this path.
+int rt_denoise_noalloc(rt_context* ctx, const float* d_rgb_in, float* d_rgb_out, int32_t width, int32_t height, const float* d_albedo,
+                       const float* d_normal) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!d_rgb_in || !d_rgb_out || width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID, "bad denoise arguments");
+  if ((long long)width * height > (long long)RT_NOALLOC_MAX_PIXELS)
+    return fail(ctx, RT_ERR_UNSUPPORTED, "rt_denoise_noalloc: width * height exceeds the fixed working array (1048576 pixels); use rt_denoise");
+  if (!ctx->noalloc_ptr) return fail(ctx, RT_ERR_DEVICE, "rt_denoise_noalloc: the working array has no device address");
+  quiesce(ctx);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)width * height;
+  // four RGBA images of RT_NOALLOC_MAX_PIXELS each; a call writes every element it later reads (pack, then each pass
+  // writes all n pixels of its output), so nothing left by an earlier call is ever read
+  float4* img = (float4*)ctx->noalloc_ptr;
+  float4 *a = img, *b = img + RT_NOALLOC_MAX_PIXELS, *alb = nullptr, *nrm = nullptr;
+  if (d_albedo) { alb = img + 2 * (size_t)RT_NOALLOC_MAX_PIXELS; LAUNCH(k_dn_pack, n, d_albedo, alb, (uint32_t)n); }
+  if (d_normal) { nrm = img + 3 * (size_t)RT_NOALLOC_MAX_PIXELS; LAUNCH(k_dn_pack, n, d_normal, nrm, (uint32_t)n); }
+  LAUNCH(k_dn_pack, n, d_rgb_in, a, (uint32_t)n);
+  float4* res = denoise_passes(ctx, width, height, a, b, alb, nrm, false);
+  LAUNCH(k_dn_unpack, n, (const float4*)res, d_rgb_out, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
