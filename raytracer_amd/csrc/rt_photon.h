@@ -336,6 +336,7 @@ struct Collected {
   uint32_t ei[RT_SEL];
   V3 raw;                // sum of (8-bit colour) x power below the bracket; Color24::ToColor's / 255 is applied to the sum
   uint32_t n_below, n_all;
+  float lo, hi;          // the bracket
   float max_d;           // largest d' among the photons below the bracket, and which photon that is
   uint32_t max_i;
 };
@@ -349,6 +350,7 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
   for (int i = 0; i < RT_SEL; i++) { C.ed[i] = RT_BIG; C.ei[i] = 0; }
   C.raw = v3(0, 0, 0);
   C.n_below = 0; C.n_all = 0;
+  C.lo = lo; C.hi = hi;
   C.max_d = -1.0f; C.max_i = 0;
   auto insert_sorted = [&](float nd, uint32_t ni) {
 #pragma unroll
@@ -416,6 +418,24 @@ RT_DEV V3 photon_finish(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
     float d_k = C.max_d, d_k1 = RT_BIG;
     uint32_t i_k = C.max_i, i_k1 = 0;
     bool have_k1 = false;
+    if (C.n_below < K && j_k >= RT_SEL) {
+      // The k-th nearest lies beyond the sorted list: the bracket holds more than RT_SEL photons that no threshold could
+      // separate — equal d' values (photons at one position), or values a float apart.  Which of them belong to the k
+      // nearest is then a matter of ties (resolved by heap history in the reference, photonmap.h:375-411): take the
+      // first k - n_below of them in visiting order, with the bound at the bracket's upper end (within float spacing of
+      // every one of them).  No exception test: it needs the k-th distance exactly.
+      uint32_t need = K - C.n_below, taken = 0;
+      V3 extra = v3(0, 0, 0);
+      photon_walk_pre(M, pos, normal, normScale, C.hi, hm, visits, [&](float d2, uint32_t, float4 pa, float4 pb) {
+        if (d2 >= C.lo && taken < need) { extra = extra + photon_power(pa, pb); taken++; }
+      });
+      sum = sum + extra;
+      guess = C.hi * 1.25f;
+      hint = C.hi;
+      float area_w = RT_PI_F * C.hi;
+      if (area_w > 0.0f) sum = sum * (1.0f / area_w);
+      return sum;
+    }
 #pragma unroll
     for (int i = 0; i < RT_SEL; i++) {
       if ((uint32_t)i <= j_k && C.n_below < K && C.ed[i] < RT_BIG) {
@@ -458,11 +478,17 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
   // ---- bracket [lo, hi) of the (k+1)-th smallest d': C(lo) <= k and C(hi) >= k + 1, C(t) = #{eligible, d' < t}
-  float lo = 0.0f, hi = guess > 0.0f && guess < r2 ? guess : r2 * 0.25f;
+  // (a guess far below the radius — the lane's previous lookup sat in a dense cluster — is raised to a floor: every step
+  // up from it costs a walk)
+  float lo = 0.0f, hi = guess > 0.0f && guess < r2 ? fmaxf(guess, r2 * 1e-9f) : r2 * 0.25f;
   uint32_t c_lo = 0, c_hi = 0;
   bool hi_known = false, all = false;
-  for (int iter = 0; iter < 12; iter++) {
+  // Invariants: C(lo) = c_lo <= k always; after a counting walk that does not grow, C(hi) = c_hi >= k + 1.  Growing steps
+  // are not limited: each multiplies hi by >= 1.25 and the step that reaches radius^2 ends the search either way.  Only
+  // narrowing steps count against the cap (16x each: twelve of them are finer than float spacing).
+  for (int narrowed = 0;;) {
     if (hi_known && c_hi - c_lo <= RT_SEL) break;
+    if (hi_known && narrowed >= 12) break;
     float t[RT_SEL];
     uint32_t c[RT_SEL];
     const float step = (hi - lo) * (1.0f / RT_SEL);
@@ -480,7 +506,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
     hi_known = true;
     if (c_hi < K + 1) {
       if (hi == r2) { all = true; lo = r2; break; }  // at most k eligible photons in all: the result is all of them
-      if (c_hi <= K) { lo = hi; c_lo = c_hi; }
+      lo = hi; c_lo = c_hi;
       // too small: grow by the areal extrapolation of the count (photons lie on surfaces), with a margin
       float grow = c_hi >= 8 ? 1.3f * (float)(K + 1) / (float)c_hi : 4.0f;
       hi = hi * (grow > 1.25f ? grow : 1.25f);
@@ -488,6 +514,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
       hi_known = false;
       continue;
     }
+    narrowed++;
     float nlo = lo, nhi = hi;
     uint32_t nclo = c_lo, nchi = c_hi;
 #pragma unroll

@@ -186,3 +186,49 @@ def check_gather_hints(r, scene, n_photons=3000, w=64, h=36, spp=2, tol=2e-6):
     same(other_off, other, "hints from other samples changed the frame")
     assert n_warm < 0.8 * n_off, f"warm hints save no walks: {n_warm} vs {n_off} photon visits"
     return n_cold, n_warm, n_off
+
+
+def check_gather_bracket_search(r, scene):
+    """The bracket search of the from-scratch lookup (rt_photon.h photon_estimate) where it is hardest.
+    (1) A lane whose previous lookup sat in a dense cluster carries a tiny radius guess into a sparse region: the search has
+        to grow by seven orders of magnitude (growing steps must not be capped).
+    (2) More than 16 photons at ONE position among the k nearest: no threshold separates them (the wide-bracket path)."""
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    rng = np.random.default_rng(5)
+    cluster = synthetic_photons(3000, seed=1)
+    cluster["position"] = (rng.normal(scale=3e-4, size=(3000, 3))).astype(np.float32)
+    sparse = synthetic_photons(600, seed=2)
+    sparse["position"][:, 0] += 20.0          # a 10-unit box, 20 units away from the cluster
+    ph = np.concatenate([cluster, sparse])
+    r.SetPhotonMap(0, ph)
+    orc.photons_set(0, ph)
+    n = 64
+    P = np.zeros((n, 3), np.float32)
+    P[1::2] = (rng.random((n // 2, 3), dtype=np.float32) * np.float32(8.0) - np.float32(4.0)) + np.array([20.0, 0, 0], np.float32)
+    N = np.zeros((n, 3), np.float32)
+    N[:, 2] = 1.0
+    for k in (16, 128):
+        g = r.EstimateIrradiance(0, P, N, radius=3.0, ellipticity=1.0, k=k)
+        c = orc.photon_gather(0, P, N, radius=3.0, ellipticity=1.0, k=k)
+        assert (c[0::2] > 0).any() and (c[1::2] > 0).any()
+        _gather_agrees(g, c, f"cluster / sparse alternation, k={k}")
+    # (2) 40 identical photons (same position, direction, power) near the query, k = 32
+    same = synthetic_photons(40, seed=3)
+    same[:] = same[0]
+    same["position"] = np.array([0.25, -0.5, 0.0], np.float32)
+    rest = synthetic_photons(500, seed=4)
+    ph = np.concatenate([rest[:250], same, rest[250:]])
+    r.SetPhotonMap(0, ph)
+    orc.photons_set(0, ph)
+    P = (np.array([0.25, -0.5, 0.0], np.float32) + rng.normal(scale=0.05, size=(50, 3))).astype(np.float32)
+    N = np.zeros((50, 3), np.float32)
+    N[:, 2] = 1.0
+    for k in (8, 32, 40):
+        g = r.EstimateIrradiance(0, P, N, radius=2.0, ellipticity=1.0, k=k)
+        c = orc.photon_gather(0, P, N, radius=2.0, ellipticity=1.0, k=k)
+        scale = np.maximum(np.abs(c).max(axis=1, keepdims=True), 1e-30)
+        rel = (np.abs(g - c) / scale).max(axis=1)
+        # ties among different photons are resolved by heap history in the reference: the sets may differ by the photons at
+        # the k-th distance, never by more
+        assert np.median(rel) <= 2e-5 and rel.max() <= 2.5 / k, f"identical photons, k={k}: {rel.max()}"

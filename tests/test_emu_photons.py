@@ -49,3 +49,7 @@ def test_photon_render(emu):
 
 def test_gather_hints_change_walks_only(emu):
     pc.check_gather_hints(emu, Scene.load(scene_path("cornell_box.xml")), n_photons=4000, w=48, h=27, spp=2)
+
+
+def test_gather_bracket_search_growth_and_ties(emu):
+    pc.check_gather_bracket_search(emu, Scene.load(scene_path("cornell_box.xml")))

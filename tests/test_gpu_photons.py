@@ -14,6 +14,10 @@ def test_gather_matches_reference_heap(gpu_renderer):
                                         n_queries=4096)
 
 
+def test_gather_bracket_search_growth_and_ties(gpu_renderer):
+    pc.check_gather_bracket_search(gpu_renderer, Scene.load(scene_path("cornell_box.xml")))
+
+
 def test_photon_maps_match_sequential_emitter(gpu_renderer):
     n = pc.check_photon_maps_match_sequential_emitter(gpu_renderer, Scene.load(scene_path("cornell_box.xml")),
                                                       n_photons=20000, exact=False)
