@@ -170,8 +170,8 @@ def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
     import numpy as np
     if p.photons:   # the comparison isolates rendering: the oracle gathers from the device's photons
         renderer.BuildPhotonMaps(p)
-        orc.photons_set(0, renderer.GetPhotonMap())
-        orc.photons_set(1, renderer.GetCausticsMap())
+        orc.photons_set_tree(0, renderer.GetPhotonTree(0))
+        orc.photons_set_tree(1, renderer.GetPhotonTree(1))
         cpu_img = orc.render(p, cores)
     g = renderer.Render(p)
     covered = cpu_img.sample_count > 0

@@ -229,7 +229,9 @@ typedef struct rt_counters {
 /* RT_K_TRACE_CLOSEST / RT_K_SHADOW: first phase (instance table: spheres, planes, mesh world boxes);
  * RT_K_TRACE_MESH / RT_K_SHADOW_MESH: second phase (BVH walk of the rays that reach a mesh). */
 enum { RT_K_RAYGEN = 0, RT_K_TRACE_CLOSEST, RT_K_SHADE, RT_K_SHADOW, RT_K_ACCUM, RT_K_PHOTON_TRACE, RT_K_PHOTON_GATHER, RT_K_DENOISE,
-       RT_K_TRACE_MESH, RT_K_SHADOW_MESH, RT_K_COUNT };
+       RT_K_TRACE_MESH, RT_K_SHADOW_MESH,
+       RT_K_PHOTON_BUILD, /* kd-tree build of the photon maps (PrepareForIrradianceEstimation): sorts + level kernels, one entry per build */
+       RT_K_COUNT };
 /* HIP-event timing of the library's own kernels on its own stream. */
 typedef struct rt_profile {
   double ms[RT_K_COUNT];
@@ -287,6 +289,10 @@ int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_ac
 int rt_photons_build(rt_context* ctx, const rt_render_params* params);
 /* GetPhotonMap / GetCausticsMap (raytracer.h:41-42): which = 0 global, 1 caustics. */
 int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n);
+/* The same map after PhotonMap::PrepareForIrradianceEstimation (photonmap.h:176-198): the left-balanced kd-tree in heap
+ * order, entry i of `out` = node i + 1 (what PhotonMap::GetPhotons() points at once the map is balanced, photonmap.h:109;
+ * the viewer's photon display reads it, viewport.cpp:441-481).  The split axis is in the low two bits of `plane`. */
+int rt_photons_download_tree(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n);
 /* Replaces one map by caller-supplied photons in insertion order, powers already scaled (what a host that traced
  * its own photons through PhotonMap::AddPhoton + ScalePhotonPowers would hold, photonmap.h:82,158-172), then
  * PrepareForIrradianceEstimation (photonmap.h:176-198). */

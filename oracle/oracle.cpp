@@ -1653,6 +1653,26 @@ int orc_photons_set(orc_scene* s, int which, const rt_photon* photons, int32_t n
   s->photons_built = true;
   return 0;
 }
+// The balanced map in heap order, entries 1 .. stored (photonmap.h:109 after PrepareForIrradianceEstimation).
+int orc_photons_tree(const orc_scene* s, int which, rt_photon* out, int32_t capacity) {
+  const PhotonMapO& m = which ? s->cmap : s->pmap;
+  if (!m.balanced) return 0;
+  int n = std::min<int>(m.stored, capacity);
+  if (n > 0) std::memcpy(out, m.photons.data() + 1, (size_t)n * sizeof(rt_photon));
+  return n;
+}
+// Installs an already balanced map (heap order, tree[i] = node i + 1): lets a test gather from exactly the tree another
+// builder produced, so that a comparison of lookups does not depend on how equal coordinates were dealt left and right.
+int orc_photons_set_tree(orc_scene* s, int which, const rt_photon* tree, int32_t n) {
+  PhotonMapO& m = which ? s->cmap : s->pmap;
+  m.photons.assign((size_t)n + 2, rt_photon{});
+  for (int i = 0; i < n; i++) m.photons[(size_t)i + 1] = tree[i];
+  m.stored = n;
+  m.half_stored = n / 2 - 1;
+  m.balanced = true;
+  s->photons_built = true;
+  return 0;
+}
 void orc_photon_gather(const orc_scene* s, int which, const float* P, const float* N, size_t n, float radius,
                        float ellipticity, int k, float* irradiance) {
   const PhotonMapO& m = which ? s->cmap : s->pmap;

@@ -44,6 +44,9 @@ int orc_photons_count(const orc_scene* s, int which);
 int orc_photons_download(const orc_scene* s, int which, rt_photon* out, int32_t capacity);
 /* Replace a map by caller-supplied photons (already scaled); balances the kd-tree. */
 int orc_photons_set(orc_scene* s, int which, const rt_photon* photons, int32_t n);
+/* The balanced map in heap order (entry i = node i + 1), and installing one that is already balanced. */
+int orc_photons_tree(const orc_scene* s, int which, rt_photon* out, int32_t capacity);
+int orc_photons_set_tree(orc_scene* s, int which, const rt_photon* tree, int32_t n);
 void orc_photon_gather(const orc_scene* s, int which, const float* P, const float* N, size_t n, float radius,
                        float ellipticity, int k, float* irradiance);
 

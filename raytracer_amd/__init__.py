@@ -220,6 +220,14 @@ class Renderer:
                     "rt_photons_download")
         return out[:n.value].copy()
 
+    def GetPhotonTree(self, which, capacity=1 << 22):
+        """The balanced map in heap order (node i + 1 at index i): PhotonMap::GetPhotons() after PrepareForIrradianceEstimation."""
+        out = np.zeros(capacity, dtype=PHOTON_DTYPE)
+        n = C.c_int32()
+        self._check(self._lib.rt_photons_download_tree(self._ctx, which, out.ctypes.data, capacity, C.byref(n)),
+                    "rt_photons_download_tree")
+        return out[:n.value].copy()
+
     def GetPhotonMap(self):
         return self._photons(0)
 

@@ -16,7 +16,7 @@ RT_PRIM_NONE, RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_MESH = 0, 1, 2, 3
 RT_SAMPLER_PHILOX, RT_SAMPLER_PCG_HALTON = 0, 1
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECT, RT_LIGHT_POINT = 1, 2, 3
 RT_K_NAMES = ["raygen", "trace_closest", "shade", "shadow", "accum", "photon_trace", "photon_gather", "denoise", "trace_mesh",
-              "shadow_mesh"]
+              "shadow_mesh", "photon_build"]
 
 
 class rt_mat34(C.Structure):
@@ -194,7 +194,7 @@ CORE_SYMBOLS = [
     "rt_render", "rt_render_begin", "rt_render_poll", "rt_render_wait", "rt_render_accumulate", "rt_resolve",
     "rt_photons_build", "rt_photons_download", "rt_photons_set", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
     "rt_counters_reset", "rt_counters_get", "rt_profile_enable", "rt_profile_reset", "rt_profile_get",
-    "rt_render_params_default", "rt_set_option", "rt_debug_alloc_count", "rt_denoise_noalloc",
+    "rt_render_params_default", "rt_set_option", "rt_debug_alloc_count", "rt_denoise_noalloc", "rt_photons_download_tree",
 ]
 HOST_SYMBOLS = [
     "rth_scene_load_file", "rth_scene_load_string", "rth_scene_free", "rth_last_error", "rth_scene_desc",
@@ -257,6 +257,7 @@ def bind_core(lib):
     lib.rt_resolve.argtypes = [vp, C.POINTER(rt_render_params), vp, C.POINTER(rt_framebuffer)]
     lib.rt_photons_build.argtypes = [vp, C.POINTER(rt_render_params)]
     lib.rt_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rt_photons_download_tree.argtypes = [vp, C.c_int, vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.rt_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.rt_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
     lib.rt_denoise.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp]

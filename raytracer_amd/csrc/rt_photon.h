@@ -37,7 +37,8 @@ struct PhotonTraceP {
 };
 struct PhotonOut {
   float4* rec[2];          // 2 float4 per record
-  uint2* key[2];           // (photon path, bounce)
+  uint2* key[2];           // (photon path - first, ordinal among the path's deposits into this map)
+  uint2* per_path;         // [count]: deposits of each path into the global / the caustics map
   uint32_t* count;         // [2]
   uint32_t* overflow;
   const int32_t* plights;  // indices of the photon-source lights (Light::IsPhotonSource, lights.h:63)
@@ -83,6 +84,8 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 
     // RayTracer::TracePhoton (RayTracer.cpp:296-334), iterative; MtlBlinn::GenerateSample (materials.cpp:335-390)
     int prevLobe = 0;
+    uint32_t n_dep[2] = {0u, 0u};   // deposits of this path so far, per map: a deposit's place in insertion order follows from
+                                    // (path, ordinal) and the counts of the paths before it (k_photon_place)
     for (int bounce = 0; bounce < PP.max_bounces; bounce++) {
       Hit h;
       rays++;
@@ -149,11 +152,12 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
             O.rec[which][2 * (size_t)at] = a;
             O.rec[which][2 * (size_t)at + 1] = b;
             uint2 k;
-            k.x = e; k.y = (uint32_t)bounce;
+            k.x = t; k.y = which ? n_dep[1] : n_dep[0];
             O.key[which][at] = k;
           } else {
             *O.overflow = 1u;
           }
+          if (which) n_dep[1]++; else n_dep[0]++;
         }
       }
       prevLobe = lobe;
@@ -161,6 +165,9 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
       d = newDir;
       c = newC;
     }
+    uint2 nd;
+    nd.x = n_dep[0]; nd.y = n_dep[1];
+    O.per_path[t] = nd;
   }
   if (CNT) {
     cnt.flush(O.counters);
@@ -727,20 +734,20 @@ RT_KERNEL(k_api_photon_gather, DPhotonMap M, const float* P, const float* N, uin
 struct PhotonState {
   bool built = false;
   uint32_t key[8] = {0};   // parameters the maps were built with
-  void* d_map[2] = {nullptr, nullptr};
-  size_t d_cap[2] = {0, 0};   // photons the device buffers hold
+  void* d_raw[2] = {nullptr, nullptr};    // insertion order, powers scaled (what GetPhotonMap()'s array holds before balancing)
+  void* d_tree[2] = {nullptr, nullptr};   // the kd-tree in heap order, count + 2 entries (PrepareForIrradianceEstimation's result)
+  size_t raw_cap[2] = {0, 0}, tree_cap[2] = {0, 0};   // photons the device buffers hold
   int32_t count[2] = {0, 0};
   uint32_t emitted = 0;
-  std::vector<rt_photon> raw[2];  // insertion order, powers scaled (what GetPhotonMap()'s array holds before balancing)
 };
 
 static inline void photon_state_free(PhotonState& s) {
   for (int i = 0; i < 2; i++) {
-    if (s.d_map[i]) (void)hipFree(s.d_map[i]);
-    s.d_map[i] = nullptr;
-    s.d_cap[i] = 0;
+    if (s.d_raw[i]) (void)hipFree(s.d_raw[i]);
+    if (s.d_tree[i]) (void)hipFree(s.d_tree[i]);
+    s.d_raw[i] = s.d_tree[i] = nullptr;
+    s.raw_cap[i] = s.tree_cap[i] = 0;
     s.count[i] = 0;
-    s.raw[i].clear();
   }
   s.built = false;
 }

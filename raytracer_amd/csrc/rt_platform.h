@@ -95,8 +95,14 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 RT_DEV uint32_t rt_atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 RT_DEV void rt_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 RT_DEV void rt_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+RT_DEV void rt_atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+RT_DEV void rt_atomic_max_u32(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+RT_DEV uint32_t rt_clz(uint32_t v) { return (uint32_t)__clz((int)v); }
 #else
 RT_DEV uint32_t rt_atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 RT_DEV void rt_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }
 RT_DEV void rt_atomic_add_f32(float* p, float v) { *p += v; }
+RT_DEV void rt_atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+RT_DEV void rt_atomic_max_u32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+RT_DEV uint32_t rt_clz(uint32_t v) { return v ? (uint32_t)__builtin_clz(v) : 32u; }
 #endif

@@ -4,6 +4,7 @@
 // single-threaded host emulation used by CPU-side unit tests only; see rt_platform.h.)
 #include "rt_kernels.h"
 #include "rt_photon.h"
+#include "rt_photon_build.h"
 #include "rt_denoise.h"
 
 #include <algorithm>
@@ -19,6 +20,9 @@
 #include <vector>
 
 #include "rtcore.h"
+#ifndef RT_EMU
+#include "rt_sort.h"
+#endif
 
 // ------------------------------------------------------------------------------------------------ helpers
 #define HIP_TRY(expr)                                                                            \
@@ -104,7 +108,7 @@ struct Options {
 
 // grow-only device buffers the entry points reuse from call to call (no hipMalloc / hipFree in the steady state)
 enum { SC_ACCUM = 0, SC_RES_RGB, SC_RES_RAD, SC_RES_CNT, SC_API_A, SC_API_B, SC_API_C, SC_DN_RGB, SC_DN_A, SC_DN_B, SC_DN_ALB, SC_DN_NRM,
-       SC_PH_REC0, SC_PH_REC1, SC_PH_KEY0, SC_PH_KEY1, SC_PH_MISC, SC_PH_PL, SC_COUNT };
+       SC_PH, SC_KD, SC_COUNT };
 
 struct rt_context {
   int device = 0;
@@ -861,108 +865,155 @@ void collect_profile(rt_context* ctx, const std::vector<uint32_t>& counts) {
   ctx->ev_used.clear();
 }
 
-// ---- photon pass (RayTracer::GeneratePhotons, RayTracer.cpp:262-294)
+// ---- photon pass (RayTracer::GeneratePhotons, RayTracer.cpp:262-294); kernels in rt_photon.h / rt_photon_build.h
 
-// PhotonMap::BalanceSegment (photonmap.h:202-264) on the host, as the reference does it: the left-balanced kd-tree in
-// heap order.  `ph` is 1-based (slot 0 unused), `bal` receives the tree.
-// The two sub-segments are disjoint ranges of `ph` and disjoint subtrees of `bal`, so the top `par` levels of the
-// recursion run their left halves on threads of their own (the result does not depend on it).
-void photon_balance_segment(std::vector<rt_photon>& ph, std::vector<rt_photon>& bal, const float* bmin, const float* bmax,
-                            int index, int start, int end, int par = 0) {
-  int median = 1;
-  while ((4 * median) <= (end - start + 1)) median += median;
-  if ((3 * median) <= (end - start + 1)) {
-    median += median;
-    median += start - 1;
-  } else {
-    median = end - median + 1;
+// One slab of device memory cut into 256-byte aligned pieces.
+struct Carver {
+  unsigned char* base = nullptr;
+  size_t used = 0;
+  template <class T>
+  T* take(size_t count) {
+    T* p = base ? (T*)(base + used) : nullptr;
+    used += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
   }
-  int axis = 2;
-  float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
-  if (dx > dy) {
-    if (dx > dz) axis = 0;
-  } else if (dy > dz) {
-    axis = 1;
-  }
-  int left = start, right = end;
-  while (right > left) {
-    const float v = ph[right].position[axis];
-    int i = left - 1, j = right;
-    while (ph[++i].position[axis] < v) {}
-    while (ph[--j].position[axis] > v && j > left) {}
-    while (i < j) {
-      std::swap(ph[i], ph[j]);
-      while (ph[++i].position[axis] < v) {}
-      while (ph[--j].position[axis] > v && j > left) {}
-    }
-    std::swap(ph[i], ph[right]);
-    if (i >= median) right = i - 1;
-    if (i <= median) left = i + 1;
-  }
-  bal[index] = ph[median];
-  bal[index].plane = (uint8_t)((bal[index].plane & 0x8) | (axis & 0x3));
-  std::thread left_worker;
-  float tmax[3] = {bmax[0], bmax[1], bmax[2]};
-  if (median > start) {
-    if (start < median - 1) {
-      tmax[axis] = bal[index].position[axis];
-      if (par > 0 && median - start > 4096)
-        left_worker = std::thread([&, index, start, median, par] { photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1, par - 1); });
-      else
-        photon_balance_segment(ph, bal, bmin, tmax, 2 * index, start, median - 1, 0);
-    } else {
-      bal[2 * index] = ph[start];
-    }
-  }
-  if (median < end) {
-    if (median + 1 < end) {
-      float tmin[3] = {bmin[0], bmin[1], bmin[2]};
-      tmin[axis] = bal[index].position[axis];
-      photon_balance_segment(ph, bal, tmin, bmax, 2 * index + 1, median + 1, end, par > 0 ? par - 1 : 0);
-    } else {
-      bal[2 * index + 1] = ph[end];
-    }
-  }
-  if (left_worker.joinable()) left_worker.join();
+};
+
+template <class Load>
+void scan_u2(rt_context* ctx, Load ld, uint32_t n, uint2* tiles, uint2* out) {
+  if (n == 0) return;
+  const uint32_t nt = (n + RT_SCAN_TILE - 1) / RT_SCAN_TILE;
+#ifndef RT_EMU
+  hipLaunchKernelGGL(k_scan_sums<Load>, dim3(nt), dim3(RT_BLOCK), 0, ctx->stream, ld, n, tiles);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(RT_BLOCK), 0, ctx->stream, tiles, nt);
+  hipLaunchKernelGGL(k_scan_write<Load>, dim3(nt), dim3(RT_BLOCK), 0, ctx->stream, ld, n, (const uint2*)tiles, out);
+#else
+  k_scan_write(ld, n, tiles, out);
+#endif
 }
 
-// PhotonMap::PrepareForIrradianceEstimation (photonmap.h:176-198).  raw = photons in insertion order.
-void photon_balance(const std::vector<rt_photon>& raw, std::vector<rt_photon>& bal) {
-  int stored = (int)raw.size();
-  bal.assign((size_t)stored + 2, rt_photon{});
-  if (stored == 0) return;
-  std::vector<rt_photon> ph((size_t)stored + 1);
-  std::memset(&ph[0], 0, sizeof(rt_photon));  // photons[0] is a value-initialised slot: the origin joins the box
-  std::copy(raw.begin(), raw.end(), ph.begin() + 1);
-  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
-  for (int i = 1; i <= stored; i++)
-    for (int a = 0; a < 3; a++) {
-      if (bmin[a] > ph[i].position[a]) bmin[a] = ph[i].position[a];
-      if (bmax[a] < ph[i].position[a]) bmax[a] = ph[i].position[a];
-    }
-  photon_balance_segment(ph, bal, bmin, bmax, 1, 1, stored, stored >= 16384 ? 3 : 0);
-}
-
-int photon_upload_balanced(PhotonState& ps, rt_context* ctx, int which, std::vector<rt_photon>& raw, const std::vector<rt_photon>& bal) {
-  if (!ps.d_map[which] || ps.d_cap[which] < bal.size()) {
-    if (ps.d_map[which]) { (void)hipFree(ps.d_map[which]); ps.d_map[which] = nullptr; }
-    HIP_TRY(hipMalloc(&ps.d_map[which], bal.size() * sizeof(rt_photon)));
-    ps.d_cap[which] = bal.size();
-  }
-  HIP_TRY(hipMemcpy(ps.d_map[which], bal.data(), bal.size() * sizeof(rt_photon), hipMemcpyHostToDevice));
-  ps.count[which] = (int32_t)raw.size();
-  ps.raw[which].swap(raw);
+// stable sort of (key, value) pairs on bits [0, end_bit) of the key
+int sort_pairs(rt_context* ctx, void* tmp, size_t tmp_bytes, const unsigned long long* kin, unsigned long long* kout, const uint32_t* vin,
+               uint32_t* vout, size_t n, int end_bit) {
+#ifndef RT_EMU
+  if (rt_sort_pairs_u64(tmp, &tmp_bytes, kin, kout, vin, vout, n, end_bit, (void*)ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "device sort failed");
+#else
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+  const unsigned long long mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (kin[a] & mask) < (kin[b] & mask); });
+  for (size_t i = 0; i < n; i++) { kout[i] = kin[order[i]]; vout[i] = vin[order[i]]; }
+#endif
   return RT_OK;
 }
-int photon_upload_map(PhotonState& ps, rt_context* ctx, int which, std::vector<rt_photon>& raw) {
-  std::vector<rt_photon> bal;
-  photon_balance(raw, bal);
-  return photon_upload_balanced(ps, ctx, which, raw, bal);
+
+int photon_ensure_buffers(PhotonState& ps, rt_context* ctx, int which, size_t n) {
+  if (!ps.d_raw[which] || ps.raw_cap[which] < n) {
+    if (ps.d_raw[which]) { (void)hipFree(ps.d_raw[which]); ps.d_raw[which] = nullptr; ps.raw_cap[which] = 0; }
+    HIP_TRY(hipMalloc(&ps.d_raw[which], std::max<size_t>(n, 1) * sizeof(rt_photon)));
+    ctx->n_allocs++;
+    ps.raw_cap[which] = n;
+  }
+  if (!ps.d_tree[which] || ps.tree_cap[which] < n) {
+    if (ps.d_tree[which]) { (void)hipFree(ps.d_tree[which]); ps.d_tree[which] = nullptr; ps.tree_cap[which] = 0; }
+    HIP_TRY(hipMalloc(&ps.d_tree[which], (n + 2) * sizeof(rt_photon)));
+    ctx->n_allocs++;
+    ps.tree_cap[which] = n;
+  }
+  return RT_OK;
+}
+
+// PhotonMap::PrepareForIrradianceEstimation (photonmap.h:176-198) for the maps in `mask` (bit 0 global, bit 1 caustics), from
+// their insertion-order arrays ps.d_raw[] to heap-ordered kd-trees in ps.d_tree[]: everything on the device, no host pass,
+// no synchronisation (rt_photon_build.h).
+int photon_kd_build(PhotonState& ps, rt_context* ctx, unsigned mask) {
+  KdMaps M;
+  std::memset(&M, 0, sizeof M);
+  uint32_t max_n = 0;
+  for (int w = 0; w < 2; w++) {
+    if (!(mask & (1u << w))) continue;
+    // the tree's unused entries (0 and count + 1) are zero, as the reference's value-initialised vector (photonmap.h:193)
+    HIP_TRY(hipMemsetAsync(ps.d_tree[w], 0, ((size_t)ps.count[w] + 2) * sizeof(rt_photon), ctx->stream));
+    if (ps.count[w] == 0) continue;
+    const uint32_t m = M.n_maps++;
+    M.raw[m] = (const float4*)ps.d_raw[w];
+    M.tree[m] = (float4*)ps.d_tree[w];
+    M.off[m] = M.n_total;
+    M.n[m] = (uint32_t)ps.count[w];
+    M.n_total += M.n[m];
+    max_n = std::max(max_n, M.n[m]);
+  }
+  if (M.n_maps == 0) return RT_OK;
+  if (M.n_maps == 1) { M.off[1] = 0xFFFFFFFFu; M.n[1] = 0; }
+  const size_t N = M.n_total;
+  M.cap = max_n / 2 + 1;
+  const uint32_t n_tiles = (uint32_t)((3 * N + RT_SCAN_TILE - 1) / RT_SCAN_TILE);
+  size_t sort_tmp = 0;
+#ifndef RT_EMU
+  if (rt_sort_pairs_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, N, 33, nullptr) != 0) return fail(ctx, RT_ERR_DEVICE, "device sort sizing failed");
+#endif
+  // one slab, cut twice with the same sequence: first to size it, then to place the pieces
+  Carver cv;
+  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+  uint32_t *vals_in = nullptr, *L[2][3], *pos_seg[2], *bounds = nullptr;
+  uint8_t *side = nullptr, *tmp = nullptr;
+  uint2 *scan = nullptr, *tiles = nullptr;
+  KdSeg* segs[2];
+  for (int pass = 0; pass < 2; pass++) {
+    cv.used = 0;
+    keys_in = cv.take<unsigned long long>(N); keys_out = cv.take<unsigned long long>(N);
+    vals_in = cv.take<uint32_t>(N);
+    for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) L[b][a] = cv.take<uint32_t>(N);
+    pos_seg[0] = cv.take<uint32_t>(N); pos_seg[1] = cv.take<uint32_t>(N);
+    side = cv.take<uint8_t>(N);
+    scan = cv.take<uint2>(3 * N);
+    tiles = cv.take<uint2>((size_t)n_tiles + 2);
+    segs[0] = cv.take<KdSeg>((size_t)M.n_maps * M.cap); segs[1] = cv.take<KdSeg>((size_t)M.n_maps * M.cap);
+    bounds = cv.take<uint32_t>(16);
+    tmp = cv.take<uint8_t>(sort_tmp + 16);
+    if (pass == 0) {
+      void* slab;
+      int rc = grow_dev(ctx, SC_KD, cv.used, &slab);
+      if (rc) return rc;
+      cv.base = (unsigned char*)slab;
+    }
+  }
+  Timer timer(ctx, RT_K_PHOTON_BUILD);
+  // box of each map's photons and the origin (photons[0] is a zeroed slot, photonmap.h:181-190)
+  uint32_t h_bounds[12];
+  for (int k = 0; k < 12; k++) h_bounds[k] = RT_KD_KEY_ZERO;
+  HIP_TRY(hipMemcpyAsync(bounds, h_bounds, sizeof h_bounds, hipMemcpyHostToDevice, ctx->stream));
+  LAUNCH(k_kd_bounds, (N + 31) / 32, M, bounds);
+  LAUNCH(k_kd_roots, N, M, (const uint32_t*)bounds, segs[0], pos_seg[0]);
+  for (int a = 0; a < 3; a++) {   // the three sorted orders
+    LAUNCH(k_kd_keys, N, M, a, keys_in, vals_in);
+    int rc = sort_pairs(ctx, tmp, sort_tmp, keys_in, keys_out, vals_in, L[0][a], N, 33);
+    if (rc) return rc;
+  }
+  int cur = 0;
+  for (uint32_t level = 0; level == 0 || (1u << level) <= max_n / 2; level++) {
+    KdLevel V;
+    for (int a = 0; a < 3; a++) { V.L[a] = L[cur][a]; V.Ln[a] = L[cur ^ 1][a]; }
+    V.pos_seg = pos_seg[cur]; V.pos_seg_n = pos_seg[cur ^ 1];
+    V.segs = segs[cur]; V.segs_n = segs[cur ^ 1];
+    V.side = side; V.scan = scan;
+    V.first_node = 1u << level;
+    LAUNCH(k_kd_split, N, M, V);
+    KdSideLoad ld;
+    for (int a = 0; a < 3; a++) ld.L[a] = V.L[a];
+    ld.pos_seg = V.pos_seg; ld.side = side; ld.n_total = (uint32_t)N;
+    scan_u2(ctx, ld, (uint32_t)(3 * N), tiles, scan);
+    LAUNCH(k_kd_scatter, 3 * N, M, V);
+    cur ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  timer.stop((1ull << 32) + N);
+  return RT_OK;
 }
 
 DPhotonMap photon_dmap(const PhotonState& ps, int which) {
   DPhotonMap m;
-  m.ph = (const float4*)ps.d_map[which];
+  m.ph = (const float4*)ps.d_tree[which];
   m.stored = ps.count[which];
   m.half = ps.count[which] / 2 - 1;
   return m;
@@ -982,48 +1033,55 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
   for (size_t l = 0; l < ctx->lights.size(); l++)
     if (ctx->lights[l].kind == RT_LIGHT_POINT) plights.push_back((int32_t)l);  // IsPhotonSource, lights.h:63
 
-  std::vector<rt_photon> kept[2];
-  kept[0].reserve(n);
-  kept[1].reserve(n);
+  int rc;
+  for (int w = 0; w < 2; w++)
+    if ((rc = photon_ensure_buffers(ps, ctx, w, n))) return rc;
+  uint32_t kept[2] = {0, 0};
   uint32_t emitted = 0;
   const bool timing = ctx->opt.timing != 0;   // developer aid: host-side phases of the build on stderr
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_start = now(), t_kernel = 0, t_copy = 0, t_sort = 0;
+  double t_start = now();
   int n_batches = 0;
   if (!plights.empty()) {
     uint32_t batch = 1u << 16, cap_batch = 1u << 21;
-    std::vector<DevMem> tmp;
-    int rc = RT_OK;
-    struct Cleanup { std::vector<DevMem>& t; ~Cleanup() { free_pool(t); } } cleanup{tmp};
-    void *d_rec[2], *d_key[2], *d_cnt, *d_pl;
     const uint32_t per_path = 16;  // deposit records a batch may add per path before the batch is retried smaller
-    uint32_t cap = batch * per_path;
-    for (int w = 0; w < 2; w++) {
-      if ((rc = alloc_dev(ctx, tmp, (size_t)cap * 32, &d_rec[w]))) return rc;
-      if ((rc = alloc_dev(ctx, tmp, (size_t)cap * 8, &d_key[w]))) return rc;
+    const uint32_t cap = batch * per_path;
+    if (max_b > 255) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_max_bounces must be <= 255");
+    Carver cv;
+    float4* d_rec[2] = {nullptr, nullptr};
+    uint2 *d_key[2] = {nullptr, nullptr}, *d_per_path = nullptr, *d_path_base = nullptr, *d_tiles = nullptr;
+    uint32_t* d_cnt = nullptr;
+    int32_t* d_pl = nullptr;
+    for (int pass = 0; pass < 2; pass++) {
+      cv.used = 0;
+      for (int w = 0; w < 2; w++) { d_rec[w] = cv.take<float4>((size_t)cap * 2); d_key[w] = cv.take<uint2>(cap); }
+      d_per_path = cv.take<uint2>(cap_batch);
+      d_path_base = cv.take<uint2>(cap_batch);
+      d_tiles = cv.take<uint2>(cap_batch / RT_SCAN_TILE + 4);
+      d_cnt = cv.take<uint32_t>(4);
+      d_pl = cv.take<int32_t>(plights.size());
+      if (pass == 0) {
+        void* slab;
+        if ((rc = grow_dev(ctx, SC_PH, cv.used, &slab))) return rc;
+        cv.base = (unsigned char*)slab;
+      }
     }
-    if ((rc = alloc_dev(ctx, tmp, 16, &d_cnt))) return rc;
-    if ((rc = alloc_dev(ctx, tmp, plights.size() * 4, &d_pl))) return rc;
     HIP_TRY(hipMemcpyAsync(d_pl, plights.data(), plights.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<rt_photon> h_rec;
-    std::vector<uint64_t> h_key;
-    std::vector<uint32_t> order;
-    std::vector<uint64_t> sorted;
-    if (cap > (1u << 24) || max_b > 255) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_max_bounces must be <= 255");  // packed sort word
-    while ((kept[0].size() < n || kept[1].size() < n) && (long long)emitted < limit) {
+    while ((kept[0] < n || kept[1] < n) && (long long)emitted < limit) {
       uint32_t count = (uint32_t)std::min<long long>(batch, limit - emitted);
       PhotonTraceP PP;
       PP.seed_lo = RP.seed_lo; PP.seed_hi = RP.seed_hi;
       PP.first = emitted; PP.count = count;
       PP.max_bounces = max_b;
       PP.n_plights = (int32_t)plights.size();
-      PP.accept[0] = kept[0].size() < n; PP.accept[1] = kept[1].size() < n;
+      PP.accept[0] = kept[0] < n; PP.accept[1] = kept[1] < n;
       PP.cap = cap;
       PhotonOut O;
-      for (int w = 0; w < 2; w++) { O.rec[w] = (float4*)d_rec[w]; O.key[w] = (uint2*)d_key[w]; }
-      O.count = (uint32_t*)d_cnt;
-      O.overflow = (uint32_t*)d_cnt + 2;
-      O.plights = (const int32_t*)d_pl;
+      for (int w = 0; w < 2; w++) { O.rec[w] = d_rec[w]; O.key[w] = d_key[w]; }
+      O.per_path = d_per_path;
+      O.count = d_cnt;
+      O.overflow = d_cnt + 2;
+      O.plights = d_pl;
       O.counters = ctx->d_counters;
       HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
       {
@@ -1032,12 +1090,23 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
         else LAUNCH_T(k_photon_trace<false>, count, ctx->ds, PP, O);
         t.stop((1ull << 32) + count);
       }
+      // deposits -> their slots in insertion order: the sequential emitter stores them path by path, bounce by bounce, and
+      // stops storing into a map that is full (photonmap.h:158-172).  Enqueued before the batch's counts are known: if the
+      // record buffers overflowed, the batch is redone in smaller ones and what this wrote beyond `kept` is overwritten.
+      PathCountLoad pl;
+      pl.per_path = d_per_path;
+      scan_u2(ctx, pl, count, d_tiles, d_path_base);
+      PhotonPlaceP A;
+      for (int w = 0; w < 2; w++) { A.rec[w] = d_rec[w]; A.key[w] = d_key[w]; A.raw[w] = (float4*)ps.d_raw[w]; A.kept[w] = kept[w]; }
+      A.n_rec = d_cnt;
+      A.path_base = d_path_base;
+      A.n = n; A.cap = cap;
+      A.scale = 1.0f / (float)RP.n_photons;   // RayTracer.cpp:290,292: 1 / numPhotons (the map's capacity)
+      LAUNCH(k_photon_place, cap, A);
       uint32_t h_cnt[4];
-      double t0 = now();
       HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       HIP_TRY(hipGetLastError());
-      t_kernel += now() - t0;
       n_batches++;
       if (h_cnt[2]) {  // more deposits than the record buffers hold: redo these paths in smaller batches
         if (batch <= 1024) return fail(ctx, RT_ERR_OVERFLOW, "photon deposit buffer overflow");
@@ -1045,74 +1114,47 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
         cap_batch = batch;  // do not grow past a size that overflowed
         continue;
       }
-      for (int w = 0; w < 2; w++) {
-        uint32_t m = h_cnt[w];
-        if (!m || kept[w].size() >= n) continue;
-        double t1 = now();
-        h_rec.resize(m);
-        h_key.resize(m);
-        HIP_TRY(hipMemcpy(h_rec.data(), d_rec[w], (size_t)m * 32, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_key.data(), d_key[w], (size_t)m * 8, hipMemcpyDeviceToHost));
-        t_copy += now() - t1;
-        t1 = now();
-        // the sequential emitter stores deposits in (path, bounce) order and stops storing when the map is full:
-        // sort (path - first, bounce, record) packed in one word; only the part that still fits the map is needed
-        sorted.resize(m);
-        for (uint32_t i = 0; i < m; i++) {
-          uint64_t path = (uint32_t)h_key[i] - PP.first, bounce = h_key[i] >> 32;  // uint2 {path, bounce}
-          sorted[i] = (path << 32) | ((bounce & 0xffu) << 24) | i;
-        }
-        size_t want = std::min<size_t>(m, n - kept[w].size());
-        if (want < m) std::nth_element(sorted.begin(), sorted.begin() + want, sorted.end());
-        std::sort(sorted.begin(), sorted.begin() + want);
-        order.resize(want);
-        for (size_t i = 0; i < want; i++) order[i] = (uint32_t)(sorted[i] & 0xffffffu);
-        m = (uint32_t)want;
-        for (uint32_t i = 0; i < m && kept[w].size() < n; i++) kept[w].push_back(h_rec[order[i]]);
-        t_sort += now() - t1;
-      }
+      for (int w = 0; w < 2; w++)
+        if (PP.accept[w]) kept[w] = (uint32_t)std::min<unsigned long long>(n, (unsigned long long)kept[w] + h_cnt[w]);
       emitted += count;
       // deposits into a map that still accepts them decide how many paths the record buffers can take per batch
       uint32_t densest = std::max(PP.accept[0] ? h_cnt[0] : 0u, PP.accept[1] ? h_cnt[1] : 0u);
       while (batch < cap_batch && (uint64_t)densest * 8 < cap) { batch *= 2; densest *= 2; }
     }
-    if (ctx->profile_on) {
-      std::vector<uint32_t> none;
-      collect_profile(ctx, none);
-    }
   }
-  // RayTracer.cpp:290,292: powers scaled by 1 / numPhotons (the map's capacity)
-  const float scale = 1.0f / (float)RP.n_photons;
-  for (int w = 0; w < 2; w++)
-    for (auto& p : kept[w]) p.power *= scale;
-  int rc;
-  const double t_bal = now();
-  {  // PrepareForIrradianceEstimation of both maps at once (the reference balances them one after the other)
-    std::vector<rt_photon> bal[2];
-    std::thread other([&] { photon_balance(kept[1], bal[1]); });
-    photon_balance(kept[0], bal[0]);
-    other.join();
-    if ((rc = photon_upload_balanced(ps, ctx, 0, kept[0], bal[0]))) return rc;
-    if ((rc = photon_upload_balanced(ps, ctx, 1, kept[1], bal[1]))) return rc;
+  const double t_emit = now();
+  ps.count[0] = (int32_t)kept[0];
+  ps.count[1] = (int32_t)kept[1];
+  if ((rc = photon_kd_build(ps, ctx, 3u))) return rc;
+  if (timing) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::fprintf(stderr, "photon build: %.2f ms total; %d batches, %u paths; emission + placement %.2f, kd-trees %.2f\n", now() - t_start, n_batches,
+                 emitted, t_emit - t_start, now() - t_emit);
   }
-  if (timing)
-    std::fprintf(stderr, "photon build: %.2f ms total; %d batches, %u paths; wait for kernels %.2f, deposit copies %.2f, ordering %.2f, balance + upload %.2f\n",
-                 now() - t_start, n_batches, emitted, t_kernel, t_copy, t_sort, now() - t_bal);
+  if (ctx->profile_on) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> none;
+    collect_profile(ctx, none);
+  }
   ps.emitted = emitted;
   std::memcpy(ps.key, key, sizeof key);
   ps.built = true;
   return RT_OK;
 }
 
-int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
+// which: 0 / 1 the global / caustics map in insertion order (GetPhotonMap() before PrepareForIrradianceEstimation);
+// tree: the balanced array in heap order, entries 1 .. n (what GetPhotons() points at afterwards, photonmap.h:109)
+int photon_download(PhotonState& ps, rt_context* ctx, int which, bool tree, rt_photon* out, int32_t capacity, int32_t* n) {
   *n = 0;
   if (which < 0 || which > 1) return fail(ctx, RT_ERR_INVALID, "which must be 0 (global) or 1 (caustics)");
   if (!ps.built) return fail(ctx, RT_ERR_NOSCENE, "photon maps have not been built (rt_photons_build)");
-  int32_t m = (int32_t)ps.raw[which].size();
+  int32_t m = ps.count[which];
   *n = m;
-  if (out) {
+  if (out && m > 0) {
     if (capacity < m) return fail(ctx, RT_ERR_INVALID, "photon buffer too small");
-    std::memcpy(out, ps.raw[which].data(), (size_t)m * sizeof(rt_photon));
+    const rt_photon* src = tree ? (const rt_photon*)ps.d_tree[which] + 1 : (const rt_photon*)ps.d_raw[which];
+    HIP_TRY(hipMemcpyAsync(out, src, (size_t)m * sizeof(rt_photon), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   return RT_OK;
 }
@@ -1120,14 +1162,19 @@ int photon_download(PhotonState& ps, rt_context* ctx, int which, rt_photon* out,
 int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* photons, int32_t n) {
   if (which < 0 || which > 1 || n < 0 || (n && !photons)) return fail(ctx, RT_ERR_INVALID, "bad photon array");
   if (n > (1 << 26)) return fail(ctx, RT_ERR_INVALID, "more than 2^26 photons");  // the walk stack packs index << 4 | axis | state
-  std::vector<rt_photon> raw(photons, photons + n);
-  int rc = photon_upload_map(ps, ctx, which, raw);
-  if (rc) return rc;
+  int rc;
+  if ((rc = photon_ensure_buffers(ps, ctx, which, (size_t)n))) return rc;
+  if (n) HIP_TRY(hipMemcpyAsync(ps.d_raw[which], photons, (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice, ctx->stream));
+  ps.count[which] = n;
+  unsigned mask = 1u << which;
+  if (!ps.built && !ps.d_tree[1 - which]) {   // the other map starts out empty
+    if ((rc = photon_ensure_buffers(ps, ctx, 1 - which, 0))) return rc;
+    ps.count[1 - which] = 0;
+    mask = 3u;
+  }
+  if ((rc = photon_kd_build(ps, ctx, mask))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));   // (the caller's array may go away)
   if (!ps.built) {
-    if (!ps.d_map[1 - which]) {
-      std::vector<rt_photon> empty;
-      if ((rc = photon_upload_map(ps, ctx, 1 - which, empty))) return rc;
-    }
     std::memset(ps.key, 0xff, sizeof ps.key);  // caller-supplied maps: never mistaken for a built parameter set
     ps.built = true;
   }
@@ -1905,7 +1952,14 @@ int rt_photons_download(rt_context* ctx, int which, rt_photon* out, int32_t capa
   if (!ctx || !n) return RT_ERR_INVALID;
   quiesce(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
-  return photon_download(ctx->photons, ctx, which, out, capacity, n);
+  return photon_download(ctx->photons, ctx, which, false, out, capacity, n);
+}
+
+int rt_photons_download_tree(rt_context* ctx, int which, rt_photon* out, int32_t capacity, int32_t* n) {
+  if (!ctx || !n) return RT_ERR_INVALID;
+  quiesce(ctx);
+  HIP_TRY(hipSetDevice(ctx->device));
+  return photon_download(ctx->photons, ctx, which, true, out, capacity, n);
 }
 
 int rt_photons_set(rt_context* ctx, int which, const rt_photon* photons, int32_t n) {

@@ -40,6 +40,8 @@ def load():
     lib.orc_photons_count.argtypes = [vp, C.c_int]
     lib.orc_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.orc_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
+    lib.orc_photons_tree.argtypes = [vp, C.c_int, vp, C.c_int32]
+    lib.orc_photons_set_tree.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.orc_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
     lib.orc_pcg32_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp]
     lib.orc_halton.restype = C.c_float
@@ -132,6 +134,16 @@ class OracleScene:
     def photons_set(self, which, photons):
         photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
         self.lib.orc_photons_set(self.h, which, photons.ctypes.data, len(photons))
+
+    def photon_tree(self, which):
+        n = self.lib.orc_photons_count(self.h, which)
+        out = np.zeros(max(n, 1), dtype=PHOTON_DTYPE)
+        n = self.lib.orc_photons_tree(self.h, which, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def photons_set_tree(self, which, tree):
+        tree = np.ascontiguousarray(tree, dtype=PHOTON_DTYPE)
+        self.lib.orc_photons_set_tree(self.h, which, tree.ctypes.data, len(tree))
 
     def photon_gather(self, which, P, N, radius=3.0, ellipticity=1.0, k=128):
         P = np.ascontiguousarray(P, dtype=np.float32)

@@ -57,6 +57,72 @@ def _gather_agrees(g, c, what):
     assert rel.max() <= 0.25, f"{what}: worst query differs by {rel.max():.3g}"
 
 
+def kd_tree_is_valid(tree):
+    """tree[i] = node i + 1 of a heap-ordered kd-tree: every node with children splits its subtrees along the axis in its
+    plane byte (left <= split <= right)."""
+    n = len(tree)
+    pos = tree["position"].astype(np.float64)
+    lo, hi = pos.copy(), pos.copy()
+    for i in range(n, 0, -1):           # children before parents
+        for c in (2 * i, 2 * i + 1):
+            if c <= n:
+                lo[i - 1] = np.minimum(lo[i - 1], lo[c - 1])
+                hi[i - 1] = np.maximum(hi[i - 1], hi[c - 1])
+    for i in range(1, n // 2 + 1):
+        a = int(tree["plane"][i - 1]) & 3
+        if a > 2:
+            return False
+        s = pos[i - 1, a]
+        if hi[2 * i - 1, a] > s:
+            return False
+        if 2 * i + 1 <= n and lo[2 * i, a] < s:
+            return False
+    return True
+
+
+def install_same_tree(r, orc, which, ph, distinct):
+    """Hands the photons to the device (rt_photons_set builds the kd-tree there) and makes the oracle gather from a tree
+    with the same visiting order.  Distinct coordinates: the oracle balances the photons itself (the reference's
+    quickselect, photonmap.h:202-264) and the two trees must be IDENTICAL.  Coordinate ties: the reference's arrangement
+    depends on its quickselect's swap history, the device's on insertion order; the device's tree must be a valid
+    left-balanced kd-tree of the same photons, and the oracle then walks that tree."""
+    r.SetPhotonMap(which, ph)
+    tree = r.GetPhotonTree(which)
+    assert len(tree) == len(ph)
+    if distinct:
+        orc.photons_set(which, ph)
+        want = orc.photon_tree(which)
+        assert tree.tobytes() == want.tobytes(), f"kd-tree differs from the reference's balance at {np.flatnonzero(tree != want)[:8]}"
+    else:
+        strip = lambda a: np.sort(np.array([bytes(x.tobytes()[:31]) for x in a]))   # (the plane byte is the tree's)
+        assert np.array_equal(strip(tree), strip(ph)), "the tree does not hold the photons it was given"
+        assert kd_tree_is_valid(tree)
+        orc.photons_set_tree(which, tree)
+    return tree
+
+
+def check_kd_tree_build(r, scene):
+    """PrepareForIrradianceEstimation on the device (rt_photon_build.h) against the oracle's restatement of the reference's
+    BalanceSegment: identical heap-ordered arrays — positions, split axes in the plane byte, one-photon children copied
+    verbatim — for every size around the powers of two (left-balancing), plus validity under coordinate ties."""
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    for n in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 32, 33, 100, 1023, 1024, 1025, 4097, 20000):
+        ph = synthetic_photons(n, seed=40 + n)
+        ph["plane"] = (np.arange(n) * 7) & 0xff       # incoming plane bytes: bit 3 survives SetPlane, leaves keep all of it
+        for which in (0, 1):
+            install_same_tree(r, orc, which, ph, distinct=True)
+    for n in (2, 7, 64, 1000, 5000):
+        install_same_tree(r, orc, 0, synthetic_photons(n, seed=3, flat=True), distinct=False)
+    same = synthetic_photons(300, seed=5)
+    same["position"] = np.array([1.0, -2.0, 0.5], np.float32)          # every coordinate tied
+    install_same_tree(r, orc, 1, same, distinct=False)
+    neg0 = synthetic_photons(200, seed=6)
+    neg0["position"][::2, 0] = -0.0                                     # -0 and +0 are one coordinate
+    neg0["position"][1::2, 0] = 0.0
+    install_same_tree(r, orc, 0, neg0, distinct=False)
+
+
 def check_gather_matches_kdtree_walk(r, scene, n_photons=5000, n_queries=400):
     """rt_photon_gather vs the oracle's restatement of PhotonMap::EstimateIrradiance (the reference's kd-tree walk and
     max-heap, step for step) on the same caller-supplied photons."""
@@ -66,8 +132,7 @@ def check_gather_matches_kdtree_walk(r, scene, n_photons=5000, n_queries=400):
                                          (1, True, 64, 50.0, 0.5), (0, False, 256, 100.0, 1.0), (0, False, 1, 1.0, 1.0),
                                          (1, False, 8, 0.7, 0.25), (0, False, 128, 0.9, 1.0)]:
         ph = synthetic_photons(n_photons, seed=11 + which, flat=flat)
-        r.SetPhotonMap(which, ph)
-        orc.photons_set(which, ph)
+        install_same_tree(r, orc, which, ph, distinct=not flat)
         P, N = queries(n_queries, seed=5, flat=flat)
         g = r.EstimateIrradiance(which, P, N, radius=radius, ellipticity=ell, k=k)
         c = orc.photon_gather(which, P, N, radius=radius, ellipticity=ell, k=k)
@@ -77,8 +142,7 @@ def check_gather_matches_kdtree_walk(r, scene, n_photons=5000, n_queries=400):
     # k + 1 .. k + 3 photons in range make the first k visited the k nearest for many queries
     for n in (9, 10, 11, 17):
         ph = synthetic_photons(n, seed=21 + n)
-        r.SetPhotonMap(0, ph)
-        orc.photons_set(0, ph)
+        install_same_tree(r, orc, 0, ph, distinct=True)
         P, N = queries(300, seed=9)
         g = r.EstimateIrradiance(0, P, N, radius=100.0, ellipticity=1.0, k=8)
         c = orc.photon_gather(0, P, N, radius=100.0, ellipticity=1.0, k=8)
@@ -86,8 +150,7 @@ def check_gather_matches_kdtree_walk(r, scene, n_photons=5000, n_queries=400):
     # edge cases: empty map, one photon, fewer photons than k, exactly k
     for n in (0, 1, 3, 8):
         ph = synthetic_photons(n, seed=3)
-        r.SetPhotonMap(0, ph)
-        orc.photons_set(0, ph)
+        install_same_tree(r, orc, 0, ph, distinct=True)
         P, N = queries(50, seed=9)
         g = r.EstimateIrradiance(0, P, N, radius=100.0, ellipticity=1.0, k=8)
         c = orc.photon_gather(0, P, N, radius=100.0, ellipticity=1.0, k=8)
@@ -116,7 +179,7 @@ def check_photon_maps_match_sequential_emitter(r, scene, n_photons=2000, emit_li
             assert ok.all(), f"map {which}: {np.count_nonzero(~ok)} photons differ in position"
         else:
             print(f"photon map {which}: {ok.mean():.5f} of the photons identical")
-            assert ok.mean() >= 0.98, f"map {which}: only {ok.mean():.3f} of the photons match"
+            assert ok.mean() >= 0.995, f"map {which}: only {ok.mean():.3f} of the photons match"   # measured on MI355X: 0.9997 / 0.9985
         assert np.abs(g["dir"][ok] - c["dir"][ok]).max() <= 1e-3
         # (powers can be negative: mult = ks * dot(newDir, N) is not clamped, materials.cpp:372)
         rel = np.abs(g["power"][ok] - c["power"][ok]) / np.maximum(np.abs(c["power"][ok]), 1e-12)
@@ -132,8 +195,10 @@ def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=45
     p = photon_params(n_photons, w=w, h=h, spp=spp)
     g = r.Render(p)
     orc = oracle_ffi.OracleScene(scene)
-    orc.photons_set(0, r.GetPhotonMap())
-    orc.photons_set(1, r.GetCausticsMap())
+    for which in (0, 1):   # traced photons tie along axes (a floor's z): the oracle walks the device's trees (install_same_tree)
+        tree = r.GetPhotonTree(which)
+        assert kd_tree_is_valid(tree) and len(tree) == len(r.GetPhotonMap() if which == 0 else r.GetCausticsMap())
+        orc.photons_set_tree(which, tree)
     c, cnt = orc.render(p, want_counters=True)
     assert cnt["gathers"] > 0
     q = photon_params(n_photons, w=w, h=h, spp=spp)
@@ -201,8 +266,7 @@ def check_gather_bracket_search(r, scene):
     sparse = synthetic_photons(600, seed=2)
     sparse["position"][:, 0] += 20.0          # a 10-unit box, 20 units away from the cluster
     ph = np.concatenate([cluster, sparse])
-    r.SetPhotonMap(0, ph)
-    orc.photons_set(0, ph)
+    install_same_tree(r, orc, 0, ph, distinct=False)
     n = 64
     P = np.zeros((n, 3), np.float32)
     P[1::2] = (rng.random((n // 2, 3), dtype=np.float32) * np.float32(8.0) - np.float32(4.0)) + np.array([20.0, 0, 0], np.float32)
@@ -219,8 +283,7 @@ def check_gather_bracket_search(r, scene):
     same["position"] = np.array([0.25, -0.5, 0.0], np.float32)
     rest = synthetic_photons(500, seed=4)
     ph = np.concatenate([rest[:250], same, rest[250:]])
-    r.SetPhotonMap(0, ph)
-    orc.photons_set(0, ph)
+    install_same_tree(r, orc, 0, ph, distinct=False)
     P = (np.array([0.25, -0.5, 0.0], np.float32) + rng.normal(scale=0.05, size=(50, 3))).astype(np.float32)
     N = np.zeros((50, 3), np.float32)
     N[:, 2] = 1.0

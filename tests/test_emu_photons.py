@@ -53,3 +53,7 @@ def test_gather_hints_change_walks_only(emu):
 
 def test_gather_bracket_search_growth_and_ties(emu):
     pc.check_gather_bracket_search(emu, Scene.load(scene_path("cornell_box.xml")))
+
+
+def test_kd_tree_build_matches_reference_balance(emu):
+    pc.check_kd_tree_build(emu, Scene.load(scene_path("cornell_box.xml")))

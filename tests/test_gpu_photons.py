@@ -14,6 +14,10 @@ def test_gather_matches_reference_heap(gpu_renderer):
                                         n_queries=4096)
 
 
+def test_kd_tree_build_matches_reference_balance(gpu_renderer):
+    pc.check_kd_tree_build(gpu_renderer, Scene.load(scene_path("cornell_box.xml")))
+
+
 def test_gather_bracket_search_growth_and_ties(gpu_renderer):
     pc.check_gather_bracket_search(gpu_renderer, Scene.load(scene_path("cornell_box.xml")))
 
