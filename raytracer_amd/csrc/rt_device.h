@@ -1143,34 +1143,31 @@ RT_DEV V3 tile_clamp(V3 uvw) {
   if (u.z < 0) u.z += 1;
   return u;
 }
+// RGB8 texel as a colour (Color24::ToColor: each channel / 255)
+RT_DEV V3 image_texel(const uint8_t* texels, int width, int x, int y) {
+  const uint8_t* t = texels + 3 * ((size_t)y * (size_t)width + (size_t)x);
+  return v3((float)t[0] / 255.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f);
+}
+// Tiling bilinear lookup (TextureFile::Eval, texture.cpp:106-132): texel (0, 0) is the image's first row, no flip; the four
+// texels around (W u, H v) weighted by the fractional parts, neighbours wrapping to the opposite edge.  The tiled
+// coordinate lies in [0, 1] — 1 itself when a tiny negative coordinate rounds up in tile_clamp's "+ 1" — so an index
+// can equal the image size and wraps once; it is never negative.  The weights and the sum keep the reference's
+// operation order (the result has to match it to the last bit for the 1e-4 colour gate on textured scenes).
 RT_DEV V3 image_eval(const DScene& S, const DImage& im, V3 uvw) {
-  int width = im.width, height = im.height;
-  if (width + height == 0) return v3(0, 0, 0);
-  V3 u = tile_clamp(uvw);
-  float x = width * u.x;
-  float y = height * u.y;
-  int ix = (int)x;
-  int iy = (int)y;
-  float fx = x - ix;
-  float fy = y - iy;
-  if (ix < 0) ix -= (ix / width - 1) * width;
-  if (ix >= width) ix -= (ix / width) * width;
-  int ixp = ix + 1;
-  if (ixp >= width) ixp -= width;
-  if (iy < 0) iy -= (iy / height - 1) * height;
-  if (iy >= height) iy -= (iy / height) * height;
-  int iyp = iy + 1;
-  if (iyp >= height) iyp -= height;
-  const uint8_t* base = S.texels + im.offset;
-  const uint8_t* p00 = base + 3 * ((size_t)iy * width + ix);
-  const uint8_t* p10 = base + 3 * ((size_t)iy * width + ixp);
-  const uint8_t* p01 = base + 3 * ((size_t)iyp * width + ix);
-  const uint8_t* p11 = base + 3 * ((size_t)iyp * width + ixp);
-  V3 c00 = v3(p00[0] / 255.0f, p00[1] / 255.0f, p00[2] / 255.0f);
-  V3 c10 = v3(p10[0] / 255.0f, p10[1] / 255.0f, p10[2] / 255.0f);
-  V3 c01 = v3(p01[0] / 255.0f, p01[1] / 255.0f, p01[2] / 255.0f);
-  V3 c11 = v3(p11[0] / 255.0f, p11[1] / 255.0f, p11[2] / 255.0f);
-  return c00 * ((1 - fx) * (1 - fy)) + c10 * (fx * (1 - fy)) + c01 * ((1 - fx) * fy) + c11 * (fx * fy);
+  const int W = im.width, H = im.height;
+  if (W + H == 0) return v3(0, 0, 0);
+  const V3 t = tile_clamp(uvw);
+  const float x = W * t.x, y = H * t.y;
+  int x0 = (int)x, y0 = (int)y;
+  const float fx = x - x0, fy = y - y0;
+  if (x0 >= W) x0 -= W;
+  if (y0 >= H) y0 -= H;
+  const int x1 = x0 + 1 < W ? x0 + 1 : x0 + 1 - W;
+  const int y1 = y0 + 1 < H ? y0 + 1 : y0 + 1 - H;
+  const uint8_t* texels = S.texels + im.offset;
+  const float gx = 1 - fx, gy = 1 - fy;
+  return image_texel(texels, W, x0, y0) * (gx * gy) + image_texel(texels, W, x1, y0) * (fx * gy) +
+         image_texel(texels, W, x0, y1) * (gx * fy) + image_texel(texels, W, x1, y1) * (fx * fy);
 }
 
 // TexturedValue<Color>::Eval.  Checker colours may be textured again (xmlload.cpp:370-374); the nesting is
