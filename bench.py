@@ -143,12 +143,46 @@ CONFIGS = {
 }
 
 
+def kernel_source_sha():
+    """Hash of the kernel sources: PMC summaries under profiles/ are valid for exactly the build they were taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_summary(config_name, src_sha):
+    """The newest profiles/r*_pmc_summary_<config>.json whose _meta.kernel_source_sha matches this build, else None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{config_name}.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_meta", {}).get("kernel_source_sha") == src_sha:
+            d["_meta"]["file"] = os.path.relpath(f, ROOT)
+            best = d
+    return best
+
+
 def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
     """The CPU oracle (reference-structured restatement: Θ(nodes) scene-graph walk, BVH visiting both children, std::thread
     over 32x32 tiles) timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
-    cores = min(16, os.cpu_count() or 1)
+    # threads: the CPU share of a one-GPU box is 16 cores (os.cpu_count() reports the whole machine there); BENCH_CPU_THREADS
+    # overrides.  Both numbers are printed.
+    nproc = os.cpu_count() or 1
+    try:
+        nproc_affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc_affinity = nproc
+    cores = int(os.environ.get("BENCH_CPU_THREADS", "0")) or min(16, nproc_affinity)
     orc = oracle_ffi.OracleScene(scene)
     WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
     p = cfg.params(0)
@@ -181,7 +215,19 @@ def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
     mean_abs = float(np.abs(g.radiance[covered][:, :3] - cpu_img.radiance[covered][:, :3]).mean())
     rays = cnt["rays_primary"] + cnt["rays_secondary"] + cnt["rays_shadow"]
     tiles = "all 32x32 tiles" if cfg.cpu_tile_stride == 1 else f"every {cfg.cpu_tile_stride}th 32x32 tile"
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    # second row: the same CPU renderer with the GPU's traversal strategy — mesh BVHs walked front to back and
+    # pruned — so that the GPU / CPU ratio is not inflated by the reference's visit-everything recursion
+    orc.set_accel(1)
+    q = cfg.params(0)
+    q.tile_begin, q.tile_stride, q.tile_count = 0, cfg.cpu_tile_stride, 0
+    q.sample_count = spp
+    t0 = time.perf_counter()
+    orc.render(q, cores)
+    dt_fast = time.perf_counter() - t0
+    orc.set_accel(0)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "nproc": nproc, "nproc_affinity": nproc_affinity,
+            "ordered_pruned_bvh": {"value": rays / dt_fast / 1e6, "unit": "Mrays/s", "cores": cores,
+                                   "note": "same oracle, mesh BVHs walked front to back with pruning (timing row only)"},
             "psnr_gpu_vs_cpu_db": psnr, "mean_abs_radiance_diff": mean_abs, "pixels_compared": int(covered.sum()),
             "sample": f"{WIDTH}x{HEIGHT}, {tiles}, {spp} spp of the same scene/params, {rays} rays in {dt:.2f} s, oracle/liboracle.so "
                       f"(reference structure: no TLAS, BVH visits both children, kd-tree + heap photon gather), {cores} threads"}
@@ -221,9 +267,13 @@ def main():
     stat_dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
     from raytracer_amd import Renderer, Scene, distributed
-    scene = cfg.scene()
+    t0 = time.perf_counter()
+    scene = cfg.scene()       # host: XML / generator, meshes, BVH build
+    scene_load_s = time.perf_counter() - t0
     r = Renderer(local_rank)
-    r.LoadScene(scene)
+    t0 = time.perf_counter()
+    r.LoadScene(scene)        # rt_scene_commit: device layout + upload
+    scene_commit_s = time.perf_counter() - t0
     p = cfg.params(rank)
     # two frame accumulators: the RCCL exchange of one frame overlaps the rendering of the next (N > 1)
     accums = [torch.zeros(WIDTH * HEIGHT * 8, dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2 if world > 1 else 1)]
@@ -296,10 +346,12 @@ def main():
         assert abs(float(img.radiance[..., 3].mean()) - n_expected) < 1e-3, "accumulator does not hold the expected samples"
 
         # SURVEY §8d algorithmic bytes / flops of the traversal and gather kernels: 48 B per ray or work item (32 B ray in,
-        # 16 B hit / occlusion out) + 32 B per BVH box tested (two per 64-byte node fetch) + 48 B per triangle slot + 96 B
-        # per instance transform pair + 32 B per photon visited; 36 flops per instance, 30 per sphere, 12 per plane, 24 per
-        # box, 51 per triangle, 20 per photon.  BVH work happens in the mesh kernels (second phase); the instance table
-        # (spheres, planes, mesh world boxes) is walked by the first-phase kernels.
+        # 16 B hit / occlusion out) + 32 B per BVH box tested (two per 64-byte node fetch) + 48 B per triangle slot + 32 B
+        # per photon visited; 36 flops per instance, 30 per sphere, 12 per plane, 24 per box, 51 per triangle, 20 per photon.
+        # The instance table (64 B + a transform chain per instance, a few KB per scene) is NOT charged per test: every
+        # lane of a wave reads the same entry through scalar loads, so its HBM traffic is the table's size, once.
+        # BVH work happens in the mesh kernels (second phase); the instance table (spheres, planes, mesh world boxes) is
+        # walked by the first-phase kernels.
         tc_rays = cnt["rays_primary"] + cnt["rays_secondary"]
         first_inst = cnt["closest_inst_tests"] - cnt["mesh_inst_tests"]
         sh_inst = cnt["inst_tests"] - cnt["closest_inst_tests"]          # shadow-ray instance tests, both phases
@@ -310,52 +362,82 @@ def main():
             # traced in registers) + k_trace_closest (secondary rays); the instance BVH's boxes count when it is used
             "k_raygen_trace+k_trace_closest": (
                 {"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
-                80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"] + 96.0 * first_inst
+                80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"]
                 + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
                 36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
-                / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0)),
+                / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
+                "k_raygen_trace"),
             "k_trace_mesh": (prof["trace_mesh"],
-                             48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"]
-                             + 96.0 * cnt["mesh_inst_tests"],
-                             36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"]),
+                             48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"],
+                             36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"],
+                             "k_trace_mesh<false>"),
+            # 84 B per shade point in, 64 B per child ray, ~48 B per shadow group (32 hard / 80 soft; groups <= shade points x lights)
+            "k_shade": (prof["shade"], 84.0 * cnt["shades"] + 64.0 * cnt["rays_secondary"]
+                        + 48.0 * min(cnt["rays_shadow"], cnt["shades"] * scene.desc.n_lights) + 16.0 * cnt["tex_evals"],
+                        (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"], "k_shade<false>"),
             # shadow rays, first phase (k_shadow_hard / k_shadow_soft): every instance test is charged here
-            "k_shadow": (prof["shadow"], 48.0 * cnt["rays_shadow"] + 96.0 * sh_inst,
+            "k_shadow": (prof["shadow"], 48.0 * cnt["rays_shadow"],
                          36.0 * sh_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * cnt["rays_shadow"]
-                         / max(tc_rays + cnt["rays_shadow"], 1)),
-            "k_shadow_mesh": (prof["shadow_mesh"], 32.0 * sh_nodes + 48.0 * sh_tris, 24.0 * sh_nodes + 51.0 * sh_tris),
-            "k_photon_gather": (prof["photon_gather"], 32.0 * cnt["photon_visits"] + 48.0 * cnt["gathers"], 20.0 * cnt["photon_visits"]),
+                         / max(tc_rays + cnt["rays_shadow"], 1), "k_shadow_soft|k_shadow_hard"),
+            "k_shadow_mesh": (prof["shadow_mesh"], 32.0 * sh_nodes + 48.0 * sh_tris, 24.0 * sh_nodes + 51.0 * sh_tris, "k_shadow_mesh"),
+            "k_photon_gather": (prof["photon_gather"], 32.0 * cnt["photon_visits"] + 48.0 * cnt["gathers"], 20.0 * cnt["photon_visits"],
+                                "k_photon_gather"),
         }
-        dom = max(kern, key=lambda k: kern[k][0]["ms"])   # the kernel with the most time in the timed region
-        tc, tc_bytes, tc_flops = kern[dom]
-        launches_per_step = tc["launches"] / max(args.steps, 1)
-        avg_ms = tc["ms"] / max(tc["launches"], 1)
-        achieved = (tc_bytes / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{dom}_{cfg.name}.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        src_sha = kernel_source_sha()
+        pmc = load_pmc_summary(cfg.name, src_sha)
+        per_kernel = {}
+        for name, (pk, k_bytes, k_flops, pmc_name) in kern.items():
+            if not pk["launches"] or pk["ms"] <= 0:
+                continue
+            lps = pk["launches"] / max(args.steps, 1)
+            avg_ms = pk["ms"] / pk["launches"]
+            e = {"ms_per_step": pk["ms"] / max(args.steps, 1), "avg_launch_ms": avg_ms, "launches_per_step": lps,
+                 "algorithmic_bytes_per_launch": k_bytes / lps, "algorithmic_flops_per_launch": k_flops / lps,
+                 "hbm_algorithmic_frac": k_bytes / lps / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "valu_algorithmic_frac": k_flops / lps / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                 "hbm_traffic_bytes_per_launch": None, "hbm_traffic_frac": None, "valu_issue_util": None,
+                 "active_lane_ratio": None, "occupancy_waves_per_simd": None, "l2_hit_rate": None}
+            m = next(((pmc or {}).get(nm) for nm in pmc_name.split("|") if (pmc or {}).get(nm)), None)
+            if m:   # counters of THIS build (the summary's kernel-source hash matches), per launch
+                if m.get("hbm_bytes_per_launch") is not None:
+                    e["hbm_traffic_bytes_per_launch"] = m["hbm_bytes_per_launch"]
+                    e["hbm_traffic_frac"] = m["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                for k in ("valu_issue_util", "active_lane_ratio", "occupancy_waves_per_simd", "l2_hit_rate"):
+                    e[k] = m.get(k)
+            per_kernel[name] = e
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])   # the kernel with the most time in the timed region
+        d = per_kernel[dom]
+        # The binding roof: the largest MEASURED utilisation when this build's counters are at hand (HBM traffic against
+        # 8 TB/s, VALU issue slots in use), otherwise the larger algorithmic fraction.  "valu": FP32 vector peak; nothing on
+        # this path is a dense contraction, so there is no MFMA roof to name.
+        if d["hbm_traffic_frac"] is not None and d["valu_issue_util"] is not None:
+            bound = "hbm" if d["hbm_traffic_frac"] >= d["valu_issue_util"] else "valu"
+        else:
+            bound = "hbm" if d["hbm_algorithmic_frac"] >= d["valu_algorithmic_frac"] else "valu"
+        if bound == "hbm":
+            achieved, peak, unit = d["algorithmic_bytes_per_launch"] / (d["avg_launch_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = d["algorithmic_flops_per_launch"] / (d["avg_launch_ms"] * 1e-3) / 1e12, VALU_PEAK_TFLOPS, "TFLOP/s"
         kernel_ms = {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items() if v["launches"]}
         out = {
             "metric": "Mrays/s", "value": total_rays_per_step * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.workload}; {WIDTH}x{HEIGHT}, {SPP_PER_STEP} spp per GPU per step, Philox seed 1",
-                       "triangles": scene.n_triangles(),
+                       "triangles": scene.n_triangles(), "scene_load_s": round(scene_load_s, 3), "scene_commit_s": round(scene_commit_s, 3),
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
                        "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": tc_bytes / max(launches_per_step, 1),
-                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                         "valu_tflops": (tc_flops / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                         "valu_frac": ((tc_flops / max(launches_per_step, 1)) / (avg_ms * 1e-3) / 1e12) / VALU_PEAK_TFLOPS if avg_ms > 0 else 0.0,
-                         "note": "algorithmic bytes per SURVEY 8d; when the scene's BVH + triangle slots fit the L2 / Infinity Cache "
-                                 "the kernel is latency / VALU bound rather than HBM bound, so the FP32 VALU fraction is reported beside it"},
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": d["hbm_traffic_bytes_per_launch"],
+                         "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
+                         "kernel_source_sha": src_sha, "pmc_summary": (pmc or {}).get("_meta", {}).get("file"),
+                         "per_kernel": per_kernel,
+                         "note": "achieved = SURVEY 8d algorithmic bytes (bound hbm) or flops (bound valu) per launch / HIP-event launch time; "
+                                 "traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from this build's PMC passes (null when no summary under "
+                                 "profiles/ carries this kernel-source hash); per_kernel lists, for every hot kernel, the algorithmic and the "
+                                 "measured HBM fraction, the algorithmic VALU fraction, VALU issue-slot utilisation, active lanes and occupancy"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, r)

@@ -440,6 +440,7 @@ struct orc_scene {
   std::vector<rt_photon> pmap_raw, cmap_raw;  // insertion order, scaled
   bool photons_built = false;
   rt_material default_mtl;
+  bool accel = false;   // orc_set_accel: ordered, pruned BVH traversal (second CPU baseline row; not the reference's structure)
 };
 
 namespace {
@@ -675,6 +676,104 @@ bool bvh_shadow(const rt_mesh& m, const Ray& ray, float t_max, uint32_t nodeID, 
   }
 }
 
+// ---- second CPU baseline row (SURVEY 8d "same data structures as GPU"): the same BVH walked front to back with a stack
+// and pruned against the best hit / the shadow ray's length, instead of the reference's visit-everything recursion.  Same
+// hits up to ties between equal t; used for TIMING only (orc_set_accel), never as the checker of a parity test.
+float aabb_entry(const Ray& ray, const rt_bvh_node& n, bool& hit) {
+  float t1 = (n.bmin[0] - ray.p.x) * ray.inv.x, t2 = (n.bmax[0] - ray.p.x) * ray.inv.x;
+  float t3 = (n.bmin[1] - ray.p.y) * ray.inv.y, t4 = (n.bmax[1] - ray.p.y) * ray.inv.y;
+  float t5 = (n.bmin[2] - ray.p.z) * ray.inv.z, t6 = (n.bmax[2] - ray.p.z) * ray.inv.z;
+  float tmin = FAST_MAX(FAST_MAX(FAST_MIN(t1, t2), FAST_MIN(t3, t4)), FAST_MIN(t5, t6));
+  float tmax = FAST_MIN(FAST_MIN(FAST_MAX(t1, t2), FAST_MAX(t3, t4)), FAST_MAX(t5, t6));
+  hit = tmax >= tmin && tmax >= 0.0f;
+  return tmin;
+}
+bool bvh_trace_accel(const rt_mesh& m, const Ray& ray, Hit& hInfo, Counters* cnt) {
+  uint32_t stack[64];
+  int sp = 0;
+  bool h0;
+  if (cnt) cnt->node_visits++;
+  (void)aabb_entry(ray, m.bvh[0], h0);
+  if (!h0) return false;
+  uint32_t cur = 0;
+  float best = BIGFLOAT, bu = 0, bv = 0;
+  int face = -1;
+  for (;;) {
+    const rt_bvh_node& n = m.bvh[cur];
+    if (n.b & RT_BVH_LEAF_BIT) {
+      uint32_t count = n.b & ~RT_BVH_LEAF_BIT;
+      for (uint32_t i = 0; i < count; i++) {
+        uint32_t tri = m.bvh_elements[n.a + i];
+        float tu, tv;
+        if (cnt) cnt->tri_tests++;
+        if (tri_intersect(m, ray, best, tri, tu, tv, 0.002f)) { face = (int)tri; bu = tu; bv = tv; }
+      }
+    } else {
+      bool hl, hr;
+      if (cnt) cnt->node_visits += 2;
+      float tl = aabb_entry(ray, m.bvh[n.a], hl), tr = aabb_entry(ray, m.bvh[n.b], hr);
+      hl = hl && tl <= best;
+      hr = hr && tr <= best;
+      if (hl && hr) {
+        bool lf = tl <= tr;
+        if (sp < 63) stack[sp++] = lf ? n.b : n.a;
+        cur = lf ? n.a : n.b;
+        continue;
+      }
+      if (hl) { cur = n.a; continue; }
+      if (hr) { cur = n.b; continue; }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  if (face < 0) return false;
+  float u = bu, v = bv, w = 1.0f - u - v;
+  V uvw(0, 0, 0);
+  if (m.uvw_idx && m.uvw) {
+    const uint32_t* ft = &m.uvw_idx[3 * (size_t)face];
+    uvw = (from3(&m.uvw[3 * (size_t)ft[0]]) * w) + (from3(&m.uvw[3 * (size_t)ft[1]]) * u) + (from3(&m.uvw[3 * (size_t)ft[2]]) * v);
+  }
+  const uint32_t* fn = &m.nrm_idx[3 * (size_t)face];
+  hInfo.N = normalized(w * from3(&m.normals[3 * (size_t)fn[0]]) + u * from3(&m.normals[3 * (size_t)fn[1]]) + v * from3(&m.normals[3 * (size_t)fn[2]]));
+  hInfo.z = best;
+  hInfo.p = ray.p + ray.dir * best;
+  hInfo.uvw = uvw;
+  hInfo.front = dot(ray.dir, hInfo.N) < 0;
+  hInfo.face = face;
+  return true;
+}
+bool bvh_shadow_accel(const rt_mesh& m, const Ray& ray, float t_max, Counters* cnt) {
+  uint32_t stack[64];
+  int sp = 0;
+  bool h0;
+  if (cnt) cnt->node_visits++;
+  float t0 = aabb_entry(ray, m.bvh[0], h0);
+  if (!h0 || t0 > t_max) return false;
+  uint32_t cur = 0;
+  for (;;) {
+    const rt_bvh_node& n = m.bvh[cur];
+    if (n.b & RT_BVH_LEAF_BIT) {
+      uint32_t count = n.b & ~RT_BVH_LEAF_BIT;
+      for (uint32_t i = 0; i < count; i++) {
+        if (cnt) cnt->tri_tests++;
+        if (tri_shadow(m, ray, m.bvh_elements[n.a + i], t_max)) return true;
+      }
+    } else {
+      bool hl, hr;
+      if (cnt) cnt->node_visits += 2;
+      float tl = aabb_entry(ray, m.bvh[n.a], hl), tr = aabb_entry(ray, m.bvh[n.b], hr);
+      hl = hl && tl <= t_max;
+      hr = hr && tr <= t_max;
+      if (hl && hr) { if (sp < 63) stack[sp++] = n.b; cur = n.a; continue; }
+      if (hl) { cur = n.a; continue; }
+      if (hr) { cur = n.b; continue; }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return false;
+}
+
 // PointLight::IntersectRay — objects.cpp:377-413 (int radius, double arithmetic)
 bool light_intersect(const rt_light& L, const Ray& ray, Hit& h, int hitSide) {
   V q = from3(L.position);
@@ -728,7 +827,7 @@ bool object_intersect(const orc_scene& S, const rt_node& n, const Ray& ray, Hit&
       return plane_intersect(ray, h, hitSide);
     case RT_PRIM_MESH: {  // TriObj::IntersectRay, objects.cpp:172-183
       Hit temp;
-      if (bvh_trace(S.d.meshes[n.mesh_id], ray, temp, 0, cnt)) {
+      if (S.accel ? bvh_trace_accel(S.d.meshes[n.mesh_id], ray, temp, cnt) : bvh_trace(S.d.meshes[n.mesh_id], ray, temp, 0, cnt)) {
         h = temp;
         return true;
       }
@@ -746,7 +845,7 @@ bool object_shadow(const orc_scene& S, const rt_node& n, const Ray& ray, float t
       if (cnt) cnt->plane_tests++;
       return plane_shadow(ray, t_max);
     case RT_PRIM_MESH:
-      return bvh_shadow(S.d.meshes[n.mesh_id], ray, t_max, 0, cnt);
+      return S.accel ? bvh_shadow_accel(S.d.meshes[n.mesh_id], ray, t_max, cnt) : bvh_shadow(S.d.meshes[n.mesh_id], ray, t_max, 0, cnt);
   }
   return false;
 }
@@ -1629,6 +1728,8 @@ void orc_trace_any(const orc_scene* s, const rt_ray* rays, const float* t_max, s
     occluded[i] = traverse_shadow(*s, r, 0, t_max ? t_max[i] : BIGFLOAT, nullptr) ? 1 : 0;
   }
 }
+
+void orc_set_accel(orc_scene* s, int on) { s->accel = on != 0; }
 
 int orc_photons_build(orc_scene* s, const rt_render_params* params, rt_counters* counters) {
   Counters c;

@@ -25,6 +25,10 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const rt_scene_desc* desc);
 void orc_scene_destroy(orc_scene* s);
 
+/* 1: the mesh BVHs are walked front to back with pruning (a CPU renderer with the GPU's traversal strategy) — for the second
+ * cpu_baseline row of bench.py ONLY; parity checks always run with 0, the reference's visit-everything recursion. */
+void orc_set_accel(orc_scene* s, int on);
+
 /* Renderer::TraceRay / TraceShadowRay restated (RayTracer.cpp:336-435). */
 void orc_trace_closest(const orc_scene* s, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits);
 void orc_trace_any(const orc_scene* s, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded);

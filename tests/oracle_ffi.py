@@ -40,6 +40,8 @@ def load():
     lib.orc_photons_count.argtypes = [vp, C.c_int]
     lib.orc_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.orc_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
+    lib.orc_set_accel.argtypes = [vp, C.c_int]
+    lib.orc_set_accel.restype = None
     lib.orc_photons_tree.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.orc_photons_set_tree.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.orc_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
@@ -85,6 +87,10 @@ class OracleScene:
         self.h = C.c_void_p(self.lib.orc_scene_create(scene.desc_ptr))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
+
+    def set_accel(self, on):
+        """Timing rows only (bench.py): ordered, pruned BVH traversal instead of the reference's recursion."""
+        self.lib.orc_set_accel(self.h, int(on))
 
     def trace_closest(self, rays, hit_side=3):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
