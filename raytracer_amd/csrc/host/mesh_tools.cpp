@@ -1,6 +1,8 @@
 #include "mesh_tools.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -92,9 +94,7 @@ struct Builder {
   std::vector<Box3> tbox;
   std::vector<float> cen;  // 3 per tri
   std::vector<uint32_t> idx;
-  std::vector<rt_bvh_node> nodes;
-  std::vector<uint32_t> elems;
-  int max_leaf, max_depth, depth_seen = 0;
+  int max_leaf, max_depth;
 
   Builder(const HostMesh& mesh, int ml, int md) : m(mesh), max_leaf(ml), max_depth(md) {
     uint32_t nf = m.n_faces();
@@ -115,7 +115,30 @@ struct Builder {
     return (double)n <= cap;
   }
 
-  uint32_t build(size_t b, size_t e, int depth) {
+  // One subtree in depth-first pre-order, node and element references relative to its own arrays.  Large subtrees are
+  // built by tasks of their own and spliced in behind their parent, which keeps the node numbering and the leaf order
+  // (the traversal tie keys) exactly those of a serial depth-first build.
+  struct Sub {
+    std::vector<rt_bvh_node> nodes;
+    std::vector<uint32_t> elems;
+    int depth_seen = 0;
+  };
+  static void splice(Sub& dst, const Sub& src) {
+    const uint32_t noff = (uint32_t)dst.nodes.size(), eoff = (uint32_t)dst.elems.size();
+    for (rt_bvh_node n : src.nodes) {
+      if (n.b & RT_BVH_LEAF_BIT) n.a += eoff;
+      else { n.a += noff; n.b += noff; }
+      dst.nodes.push_back(n);
+    }
+    dst.elems.insert(dst.elems.end(), src.elems.begin(), src.elems.end());
+    dst.depth_seen = std::max(dst.depth_seen, src.depth_seen);
+  }
+  std::atomic<int> tasks_left{0};   // worker tasks that may still be started
+
+  uint32_t build(Sub& out, size_t b, size_t e, int depth) {
+    std::vector<rt_bvh_node>& nodes = out.nodes;
+    std::vector<uint32_t>& elems = out.elems;
+    int& depth_seen = out.depth_seen;
     depth_seen = std::max(depth_seen, depth);
     uint32_t me = (uint32_t)nodes.size();
     nodes.emplace_back();
@@ -186,8 +209,22 @@ struct Builder {
         return cx < cy || (cx == cy && x < y);
       });
     }
-    uint32_t l = build(b, mid, depth + 1);
-    uint32_t r = build(mid, e, depth + 1);
+    if (n >= 65536 && tasks_left.fetch_sub(1) > 0) {
+      // the right half on a task of its own (disjoint range of idx, own output arrays), spliced in behind the left half
+      Sub right;
+      std::thread worker([&] { build(right, mid, e, depth + 1); });
+      uint32_t l = build(out, b, mid, depth + 1);
+      worker.join();
+      tasks_left.fetch_add(1);
+      uint32_t r = (uint32_t)nodes.size();
+      splice(out, right);
+      nodes[me].a = l;
+      nodes[me].b = r;
+      return me;
+    }
+    if (n >= 65536) tasks_left.fetch_add(1);   // (undo the failed claim)
+    uint32_t l = build(out, b, mid, depth + 1);
+    uint32_t r = build(out, mid, e, depth + 1);
     nodes[me].a = l;
     nodes[me].b = r;
     return me;
@@ -208,12 +245,16 @@ void HostMesh::build_bvh(int max_leaf, int max_depth) {
     return;
   }
   Builder bld(*this, max_leaf, max_depth);
-  bld.nodes.reserve(n_faces());
-  bld.elems.reserve(n_faces());
-  bld.build(0, n_faces(), 0);
-  bvh.swap(bld.nodes);
-  elems.swap(bld.elems);
-  bvh_depth = bld.depth_seen;
+  Builder::Sub root;
+  root.nodes.reserve(n_faces());
+  root.elems.reserve(n_faces());
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("RTH_BUILD_THREADS")) hw = (unsigned)std::atoi(e);
+  bld.tasks_left = (int)std::min(hw > 0 ? hw : 1u, 32u) - 1;
+  bld.build(root, 0, n_faces(), 0);
+  bvh.swap(root.nodes);
+  elems.swap(root.elems);
+  bvh_depth = root.depth_seen;
 }
 
 // ------------------------------------------------------------------ OBJ

@@ -655,10 +655,12 @@ RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs,
 
 // Every lane of a wave runs every queue-append site of an iteration (predicated), so the per-wave chunk state of
 // wave_push stays uniform; see WavePush.
-template <bool CNT>
+// MC / PH: the indirect-diffuse sampler / the photon term can be on in this pass (compiled out otherwise: the kernel is
+// held back by its registers, and a frame uses one combination throughout).
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4   // measured on the C2 bench: 2 -> 7.37 ms, 3 -> 6.52 ms, 4 -> 6.26 ms per step
 #endif
+template <bool CNT, bool MC, bool PH>
 RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
@@ -804,7 +806,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
             }
           }
           V3 local = emission;
-          if (P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
+          if (MC && P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
             V3 wc = w * kd;
             if (nonzero(wc)) {
               if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
@@ -822,7 +824,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
               c_mc.meta = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
               p_mc = true;
             }
-          } else if (P.photons) {  // materials.cpp:315-322
+          } else if (PH && P.photons) {  // materials.cpp:315-322
             wk = w * ((float)(1.0f / RT_PI_D) * kd);
             p_gather = nonzero(wk);
           }
@@ -848,8 +850,10 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         QN.h2[ci] = h2;
       }
     }
-    ci = seg_push(p_mc, QN.counts, oseg, QN.segcap, F.overflow);
-    if (ci != RT_NONE) write_child(QN, ci, c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
+    if (MC) {
+      ci = seg_push(p_mc, QN.counts, oseg, QN.segcap, F.overflow);
+      if (ci != RT_NONE) write_child(QN, ci, c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
+    }
 
     // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
     for (int li = 0; li < S.n_lights; li++) {
@@ -901,7 +905,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         }
       }
     }
-    if (P.photons) {
+    if (PH && P.photons) {
       uint32_t gi = seg_push(p_gather, GQ.counts, oseg, GQ.segcap, F.overflow);
       if (gi != RT_NONE) {
         GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));

@@ -1446,7 +1446,11 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     }
     {
       Timer t(ctx, RT_K_SHADE);
-      LAUNCH(k_shade<CNT>, ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+      const bool mc = P.mc_bounces > 0, ph = P.photons != 0;
+      if (mc && ph) LAUNCH((k_shade<CNT, true, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+      else if (mc) LAUNCH((k_shade<CNT, true, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+      else if (ph) LAUNCH((k_shade<CNT, false, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+      else LAUNCH((k_shade<CNT, false, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
     }
     if (any_hard) {

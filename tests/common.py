@@ -404,3 +404,34 @@ def check_stress_scene(r, scene, w, h, n_rays):
     occ = orc.trace_any(rays, tmax)
     assert np.array_equal(r.TraceShadowRay(rays, tmax), occ) and 0.05 < occ.mean() < 0.95
     return g, c
+
+
+def check_reference_scene_fixtures(r, w, h, strict=None):
+    """north_star: "every bundled scene renders within tolerance of the CPU reference".  tests/golden/scenes/ref_*.xml carry
+    the scene data of eight bundled reference scenes (nested transforms, direct + ambient + soft point lights, reflection /
+    refraction / absorption, nested checkerboards, image textures on objects, background and environment, depth of field,
+    nodes without material or lights, 49 glass spheres) to the GPU box; the reference's own files are read in place by
+    test_emu_parity where the checkout exists."""
+    import glob
+    import os
+    import oracle_ffi
+    from conftest import GOLDEN, ROOT
+    from raytracer_amd import Scene
+    files = sorted(glob.glob(os.path.join(GOLDEN, "scenes", "ref_*.xml")))
+    assert len(files) >= 8
+    for f in files:
+        scene = Scene.load(f, asset_dir=ROOT)
+        assert scene.warnings == 0, f
+        r.LoadScene(scene)
+        orc = oracle_ffi.OracleScene(scene)
+        p = params(w, h, spp=1, jitter=0, bounces=0)
+        g, c = r.Render(p), orc.render(p)
+        assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face), f
+        assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4, f
+        p = params(w // 2, h // 2, spp=2, jitter=1, bounces=2)
+        p.shadow_min, p.shadow_max = 4, 8
+        g, c = r.Render(p), orc.render(p)
+        if strict is not None:
+            assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict, f
+        else:
+            assert_stochastic_close(g, c, os.path.basename(f), frac=0.999)

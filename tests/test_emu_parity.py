@@ -234,3 +234,7 @@ def test_every_bundled_reference_scene_renders_like_the_oracle(emu):
         g, c = emu.Render(p), orc.render(p)
         assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 1e-4, f
         assert psnr8(g.img, c.img) >= 60.0, f"{f}: PSNR {psnr8(g.img, c.img):.1f}"
+
+
+def test_reference_scene_fixtures(emu):
+    common_checks.check_reference_scene_fixtures(emu, 64, 36, strict=1e-4)

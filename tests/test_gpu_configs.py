@@ -125,3 +125,9 @@ def test_steady_state_calls_do_not_allocate(gpu_renderer):
     for _ in range(3):
         calls()
     assert gpu_renderer.alloc_count() == before
+
+
+def test_reference_scene_fixtures(gpu_renderer):
+    """Eight bundled reference scenes (scene data fixtures) on the GPU against the oracle: ids bit-exact, colour 1e-4,
+    stochastic frames within the gate of assert_stochastic_close."""
+    cc.check_reference_scene_fixtures(gpu_renderer, 320, 180)
