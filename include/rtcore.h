@@ -285,6 +285,14 @@ int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, void* 
 /* Final division, sRGB, Color24 (RayTracer.cpp:206-216) from a device accumulator. */
 int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_accum, rt_framebuffer* fb);
 
+/* The frame's one exchange for multi-GPU hosts that do not use torch.distributed (the reference's host is C++): in-place
+ * RCCL sum-reduce of a device accumulator (W*H*8 floats, layout above) to rank `root` of `nccl_comm` (an ncclComm_t the
+ * caller created, one rank per GPU), on the context's stream; blocks until it has completed.  `nccl_reduce_fn` is the
+ * caller's ncclReduce (pass `(void*)&ncclReduce`), or NULL to look it up among the process's global symbols — librtcore
+ * does not link RCCL, so the communicator and the function always come from the same library.  The reference has no
+ * counterpart (single process, RayTracer.cpp:41-50); SURVEY 8e defines the exchange. */
+int rt_reduce_accumulators(rt_context* ctx, void* nccl_comm, void* nccl_reduce_fn, void* d_accum, int32_t width, int32_t height, int root);
+
 /* GeneratePhotons (RayTracer.cpp:262-294): emission, random walk, both maps, balance. */
 int rt_photons_build(rt_context* ctx, const rt_render_params* params);
 /* GetPhotonMap / GetCausticsMap (raytracer.h:41-42): which = 0 global, 1 caustics. */

@@ -276,6 +276,11 @@ class Renderer:
         self._check(self._lib.rt_resolve(self._ctx, C.byref(params), C.c_void_p(d_accum_ptr), C.byref(fb)), "rt_resolve")
         return self.renderImage
 
+    def reduce_accumulators(self, nccl_comm, d_accum_ptr, width, height, root=0, nccl_reduce_fn=None):
+        """rt_reduce_accumulators: in-place RCCL sum-reduce of a device accumulator (for hosts without torch.distributed)."""
+        self._check(self._lib.rt_reduce_accumulators(self._ctx, C.c_void_p(nccl_comm), C.c_void_p(nccl_reduce_fn), C.c_void_p(d_accum_ptr),
+                                                     width, height, root), "rt_reduce_accumulators")
+
     def set_option(self, name, value):
         """Developer knobs of this context (rt_set_option): tlas_min, gather_hints, frame_gb, fan_scale, timing."""
         self._check(self._lib.rt_set_option(self._ctx, name.encode(), float(value)), "rt_set_option")

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <exception>
 #include <vector>
 
 #include "rthost.h"
@@ -55,6 +56,7 @@ bool decode_png(const std::vector<uint8_t>& d, uint8_t** rgb, int* w, int* h) {
     if (i + 12 + n > d.size()) return false;
     const uint8_t* p = &d[i + 8];
     if (!std::memcmp(t, "IHDR", 4)) {
+      if (n < 13) return false;   // truncated header
       W = be32(p); H = be32(p + 4); depth = p[8]; ctype = p[9]; interlace = p[12];
     } else if (!std::memcmp(t, "PLTE", 4)) plte.assign(p, p + n);
     else if (!std::memcmp(t, "IDAT", 4)) idat.insert(idat.end(), p, p + n);
@@ -62,8 +64,14 @@ bool decode_png(const std::vector<uint8_t>& d, uint8_t** rgb, int* w, int* h) {
     i += 12 + n;
   }
   if (!W || !H || interlace) return false;
+  if ((uint64_t)W * (uint64_t)H > (1ull << 28)) return false;   // (a scene file can name any file: bound what it may allocate)
   int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!ch) return false;
+  // bit depths the PNG specification allows per colour type
+  const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                      : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                   : (depth == 8 || depth == 16);
+  if (!depth_ok) return false;
   size_t bpp_bits = (size_t)ch * depth;
   size_t stride = (W * bpp_bits + 7) / 8;
   size_t bpp = (bpp_bits + 7) / 8;
@@ -169,6 +177,7 @@ extern "C" int rth_write_png(const char* path, const uint8_t* px, int w, int h, 
 
 extern "C" int rth_read_image_rgb(const char* path, uint8_t** rgb, int* w, int* h) {
   if (!path || !rgb || !w || !h) return -1;
+  try {   // (no exception may cross the C boundary: a hostile file must fail the load, not the process)
   std::vector<uint8_t> d;
   if (!read_file(path, d)) return -1;
   size_t len = std::strlen(path);
@@ -176,6 +185,9 @@ extern "C" int rth_read_image_rgb(const char* path, uint8_t** rgb, int* w, int* 
              (path[len - 1] == 'm' || path[len - 1] == 'M');
   bool ok = ppm ? decode_ppm(d, rgb, w, h) : decode_png(d, rgb, w, h);
   return ok ? 0 : -1;
+  } catch (const std::exception&) {
+    return -1;
+  }
 }
 
 extern "C" void rth_free(void* p) { std::free(p); }

@@ -21,6 +21,7 @@
 
 #include "rtcore.h"
 #ifndef RT_EMU
+#include <dlfcn.h>
 #include "rt_sort.h"
 #endif
 
@@ -1940,6 +1941,31 @@ int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_ac
   if (!params || !d_accum || !fb) return fail(ctx, RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return resolve_internal(ctx, *params, (const float*)d_accum, fb);
+}
+
+// Multi-GPU hosts without torch (the reference is a C++ program): the frame's one exchange, an in-place RCCL sum-reduce of
+// the accumulator to `root`, enqueued on the context's stream.  RCCL is not linked: ncclReduce is the caller's — passed as a
+// function pointer, or looked up among the process's global symbols — so the communicator and the function that uses it
+// always come from the same copy of the library.
+int rt_reduce_accumulators(rt_context* ctx, void* nccl_comm, void* nccl_reduce_fn, void* d_accum, int32_t width, int32_t height, int root) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!nccl_comm || !d_accum || width <= 0 || height <= 0 || root < 0) return fail(ctx, RT_ERR_INVALID, "bad reduce arguments");
+#ifdef RT_EMU
+  return fail(ctx, RT_ERR_UNSUPPORTED, "no RCCL in the host emulation");
+#else
+  quiesce(ctx);
+  HIP_TRY(hipSetDevice(ctx->device));
+  // ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t, ncclRedOp_t, int root, ncclComm_t, hipStream_t)
+  typedef int (*reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+  reduce_fn fn = (reduce_fn)nccl_reduce_fn;
+  if (!fn) fn = (reduce_fn)dlsym(RTLD_DEFAULT, "ncclReduce");
+  if (!fn) return fail(ctx, RT_ERR_UNSUPPORTED, "ncclReduce not found: link the host against librccl or pass the function pointer");
+  const int nccl_float32 = 7, nccl_sum = 0;   // ncclFloat32 / ncclSum (nccl.h; stable ABI values)
+  int rc = fn(d_accum, d_accum, (size_t)width * (size_t)height * 8u, nccl_float32, nccl_sum, root, nccl_comm, ctx->stream);
+  if (rc != 0) return fail(ctx, RT_ERR_DEVICE, "ncclReduce failed with code " + std::to_string(rc));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+#endif
 }
 
 int rt_photons_build(rt_context* ctx, const rt_render_params* params) {

@@ -4,7 +4,14 @@ Sample split: rank r renders camera-sample indices [r*S, (r+1)*S) of every pixel
 (sum rgb, n, sum of squares, -), then one sum-reduce of the accumulators to rank 0 — the only exchange per frame.
 Tile split: rank r renders the 32x32 tiles r, r+world, r+2*world, ... (reference tileSize, raytracer.h:46); ranks own
 disjoint pixels, so the same zero-initialised sum-reduce gathers the frame.
+Hybrid (BASELINE config 5: 8 GPUs as 2 tile groups x 4 sample ranges): rank r renders the tiles of tile group r % T with the
+sample range of group r // T; the one sum-reduce still assembles the frame, because every (pixel, sample) is rendered by
+exactly one rank.
 The scene, BVH, textures (and photon maps: same Philox seed => identical maps) are replicated on every GPU.
+
+Stream order: the renderer core runs on its own HIP stream and every C-ABI call blocks until its work has finished, so
+what it wrote is visible to torch afterwards; in the other direction (torch zeroing / unpacking an accumulator that the
+next rt_render_accumulate or rt_resolve reads) the helpers here synchronise torch's current stream before they return.
 """
 import copy
 
@@ -33,6 +40,24 @@ def tile_split_params(params, rank, world):
     return p
 
 
+def hybrid_split_params(params, rank, tile_groups, sample_groups, spp_per_group):
+    """rank -> (tile group rank % tile_groups, sample group rank // tile_groups): tiles t = tg, tg + T, ... (raytracer.h:46)
+    and camera samples [sg * S, (sg + 1) * S).  tile_groups * sample_groups must be the world size."""
+    if rank < 0 or rank >= tile_groups * sample_groups:
+        raise ValueError("rank outside the tile_groups x sample_groups grid")
+    p = sample_split_params(params, rank // tile_groups, spp_per_group)
+    p.tile_begin, p.tile_stride, p.tile_count = rank % tile_groups, tile_groups, 0
+    if p.spp_max < sample_groups * spp_per_group:
+        p.spp_min = p.spp_max = sample_groups * spp_per_group
+    return p
+
+
+def _sync_torch_stream(t):
+    """torch work on `t` is finished before the renderer core's own stream touches it."""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class PendingReduce:
     """An accumulator exchange in flight (RCCL runs it on its own stream); wait() completes it on `dst`."""
 
@@ -45,6 +70,7 @@ class PendingReduce:
             self.work = None
         if self.packed is not None and self.is_dst:
             self.accum.view(-1, ACCUM_FLOATS_PER_PIXEL)[:, :4] = self.packed.view(-1, 4)
+            _sync_torch_stream(self.accum)   # the unpacked sums are in place before rt_resolve / the next render reads them
         self.packed = None
         return self.accum
 
@@ -82,5 +108,6 @@ def render_partition(renderer, params, accum, group=None, dst=0, sums_only=True,
     """Renders this rank's share into `accum` (blocking), then sums all shares on rank `dst` (no exchange for one rank).
     async_op: returns with the exchange still in flight so that the next frame's rendering overlaps it; the caller
     keeps `accum` untouched until PendingReduce.wait()."""
+    _sync_torch_stream(accum)   # (the caller's accum.zero_() has landed)
     renderer.render_accumulate(params, accum.data_ptr())
     return reduce_accumulators(accum, group=group, dst=dst, sums_only=sums_only, async_op=async_op)

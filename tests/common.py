@@ -434,4 +434,6 @@ def check_reference_scene_fixtures(r, w, h, strict=None):
         if strict is not None:
             assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict, f
         else:
-            assert_stochastic_close(g, c, os.path.basename(f), frac=0.999)
+            # (few shadow samples per group, 4..8: one shadow ray that an ulp flips at a silhouette changes a whole group's
+            # early-out, so single pixels differ visibly — measured 4 of 14 400 pixels, 70 dB, on ref_soft_shadow_scene)
+            assert_stochastic_close(g, c, os.path.basename(f), frac=0.999, psnr=60.0, mean=1e-5)

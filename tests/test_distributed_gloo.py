@@ -37,7 +37,13 @@ def _worker(rank, world, port, mode, out_path):
     r = emu_ffi.EmuRenderer()
     r.LoadScene(scene)
     base = params(W, H, spp=SPP * world, jitter=1, bounces=2)
-    p = distributed.sample_split_params(base, rank, SPP) if mode.startswith("sample") else distributed.tile_split_params(base, rank, world)
+    if mode == "hybrid":   # BASELINE config 5's partition in small: 2 tile groups x 2 sample ranges
+        base = params(W, H, spp=SPP * 2, jitter=1, bounces=2)
+        p = distributed.hybrid_split_params(base, rank, 2, world // 2, SPP)
+    elif mode.startswith("sample"):
+        p = distributed.sample_split_params(base, rank, SPP)
+    else:
+        p = distributed.tile_split_params(base, rank, world)
     if mode == "sample_pipelined":
         # bench.py's N > 1 loop: two accumulators, each frame's exchange left in flight while the next frame renders
         accs = [distributed.alloc_accumulator(W, H, "cpu") for _ in range(2)]
@@ -74,3 +80,14 @@ def test_two_rank_partition_equals_single_render(tmp_path, mode):
     else:
         assert np.allclose(d["split"], d["full"], rtol=1e-6, atol=1e-7)
         assert np.abs(d["split8"].astype(int) - d["full8"].astype(int)).max() <= 1
+
+
+def test_four_rank_hybrid_partition_equals_single_render(tmp_path):
+    """SURVEY 8e hybrid partition (C5: 2 tile groups x 4 sample ranges on 8 GPUs), here 2 x 2 on four gloo ranks: every
+    (pixel, sample) is rendered by exactly one rank and one sum-reduce assembles the frame."""
+    out = str(tmp_path / "hybrid.npz")
+    mp.spawn(_worker, args=(4, _free_port(), "hybrid", out), nprocs=4, join=True)
+    d = np.load(out)
+    assert (d["split"][..., 3] == SPP * 2).all()
+    assert np.allclose(d["split"], d["full"], rtol=1e-6, atol=1e-7)
+    assert np.abs(d["split8"].astype(int) - d["full8"].astype(int)).max() <= 1

@@ -131,3 +131,38 @@ def test_reference_scene_fixtures(gpu_renderer):
     """Eight bundled reference scenes (scene data fixtures) on the GPU against the oracle: ids bit-exact, colour 1e-4,
     stochastic frames within the gate of assert_stochastic_close."""
     cc.check_reference_scene_fixtures(gpu_renderer, 320, 180)
+
+
+def test_reduce_accumulators_over_rccl_single_rank(gpu_renderer):
+    """rt_reduce_accumulators (the C hosts' multi-GPU exchange): a one-rank RCCL communicator made through ctypes, the
+    caller's own ncclReduce handed over as a function pointer; a one-rank sum-reduce leaves the accumulator as it is.
+    (The N > 1 exchange itself is the driver's scaling run; the partition logic is covered by the gloo tests.)"""
+    import ctypes as C
+    import torch
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        path = "/opt/rocm/lib/librccl.so"
+    rccl = C.CDLL(path)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        w, h = 64, 32
+        acc = torch.arange(w * h * 8, dtype=torch.float32, device="cuda:0")
+        want = acc.clone()
+        torch.cuda.synchronize()
+        fn = C.cast(rccl.ncclReduce, C.c_void_p).value
+        gpu_renderer.reduce_accumulators(comm.value, acc.data_ptr(), w, h, root=0, nccl_reduce_fn=fn)
+        assert torch.equal(acc, want)
+        with pytest.raises(RuntimeError):
+            gpu_renderer.reduce_accumulators(0, acc.data_ptr(), w, h)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -208,3 +208,39 @@ def test_every_bundled_reference_scene_loads():
     assert s.desc.n_nodes == 2947
     s = Scene.load(os.path.join(REF_SCENES, "scene_textures.xml"))
     assert s.desc.n_images == 2 and s.desc.images[0].width == 1024
+
+
+def test_malformed_png_files_are_refused(tmp_path):
+    """a scene file can name any texture file — truncated headers, impossible bit depths and absurd sizes must
+    fail the load (return -1), not read out of bounds, divide by zero or throw through the C boundary."""
+    import ctypes as C
+    import struct
+    import zlib
+    from raytracer_amd import _ffi
+    host = _ffi.load_host()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    def png(ihdr, idat=b""):
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+    good = png(struct.pack(">IIBBBBB", 2, 2, 8, 2, 0, 0, 0), zlib.compress(b"\x00" + b"\x10" * 6 + b"\x00" + b"\x20" * 6))
+    cases = {
+        "good": (good, 0),
+        "short_ihdr": (png(struct.pack(">II", 2, 2)), -1),
+        "depth0": (png(struct.pack(">IIBBBBB", 2, 2, 0, 0, 0, 0, 0), zlib.compress(b"\x00\x00" * 2)), -1),
+        "depth3": (png(struct.pack(">IIBBBBB", 2, 2, 3, 0, 0, 0, 0), zlib.compress(b"\x00\x00" * 2)), -1),
+        "depth32": (png(struct.pack(">IIBBBBB", 2, 2, 32, 2, 0, 0, 0), zlib.compress(b"\x00" * 50)), -1),
+        "huge": (png(struct.pack(">IIBBBBB", 1 << 20, 1 << 20, 8, 2, 0, 0, 0), zlib.compress(b"\x00" * 16)), -1),
+        "truncated": (good[:40], -1),
+    }
+    for name, (data, want) in cases.items():
+        f = tmp_path / (name + ".png")
+        f.write_bytes(data)
+        rgb, w, h = C.POINTER(C.c_uint8)(), C.c_int(), C.c_int()
+        rc = host.rth_read_image_rgb(str(f).encode(), C.byref(rgb), C.byref(w), C.byref(h))
+        assert rc == want, name
+        if rc == 0:
+            assert (w.value, h.value) == (2, 2) and rgb[0] == 0x10 and rgb[6] == 0x20
+            host.rth_free(rgb)
