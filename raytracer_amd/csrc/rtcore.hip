@@ -144,6 +144,8 @@ struct rt_context {
   uint32_t* d_gather_retry = nullptr;   // GatherP::retry, retry_seed
   float* d_gather_seed = nullptr;
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
+  uint32_t* d_summary = nullptr; // k_pass_summary's output (allocated with the context)
+  uint32_t* h_summary = nullptr; // ... and its pinned host copy
   float4* d_path_rad = nullptr;
   uint32_t* d_pixels = nullptr;
   uint32_t* d_pixels2 = nullptr;
@@ -450,6 +452,18 @@ int rt_context_create(int device_id, rt_context** out) {
   if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
   ctx->d_counters = (DCounters*)p;
   (void)hipMemset(p, 0, sizeof(DCounters));
+  {  // per-pass summary (k_pass_summary): device words + their pinned host copy
+    void *ds = nullptr, *hs = nullptr;
+    if (hipMalloc(&ds, 4096) != hipSuccess || hipHostMalloc(&hs, 4096) != hipSuccess) {
+      if (ds) (void)hipFree(ds);
+      (void)hipFree(p);
+      (void)hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return RT_ERR_DEVICE;
+    }
+    ctx->d_summary = (uint32_t*)ds;
+    ctx->h_summary = (uint32_t*)hs;
+  }
   {  // this device's address of the no-allocation entry point's working array (the device is current: hipSetDevice above)
 #ifndef RT_EMU
     void* sp = nullptr;
@@ -506,6 +520,8 @@ void rt_context_destroy(rt_context* ctx) {
   photon_state_free(ctx->photons);
   if (ctx->d_gather_hints) (void)hipFree(ctx->d_gather_hints);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_summary) (void)hipFree(ctx->d_summary);
+  if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipStreamDestroy(ctx->stream);
@@ -1652,28 +1668,27 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   F.overflow = ctx->d_counts + CNT_OVERFLOW;
   F.counters = ctx->d_counters;
 
-  std::vector<uint32_t> raw(CNT_TOTAL), counts((MAX_LEVELS + 1) * CNT_KINDS);
+  constexpr uint32_t N_SLOTS = (MAX_LEVELS + 1) * CNT_KINDS;
+  std::vector<uint32_t> counts(N_SLOTS);
   double seen[7] = {0, 0, 0, 0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
   bool overflowed = false;
   auto finish_pass = [&](uint64_t paths) -> int {
-    HIP_TRY(hipMemcpyAsync(raw.data(), ctx->d_counts, CNT_TOTAL * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // the pass in 1 KB: per (level, kind) the sum and the maximum of the segment lengths + the overflow word, folded on the
+    // device and copied into pinned host memory (the full table of counters is 1 MB; copying it cost more than a C1 frame)
+    LAUNCH(k_pass_summary, N_SLOTS, (const uint32_t*)ctx->d_counts, N_SLOTS, NSEG, (uint32_t)CNT_SLAB, (uint32_t)CNT_OVERFLOW, ctx->d_summary);
+    HIP_TRY(hipMemcpyAsync(ctx->h_summary, ctx->d_summary, (2 * N_SLOTS + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
-    if (raw[CNT_OVERFLOW] == RT_WALK_ABORT) return fail(ctx, RT_ERR_DEVICE, "a traversal wave exceeded its step limit (internal error)");
-    overflowed = raw[CNT_OVERFLOW] != 0;
+    const uint32_t* sums = ctx->h_summary;
+    const uint32_t* maxs = ctx->h_summary + N_SLOTS;
+    const uint32_t ovf = ctx->h_summary[2 * N_SLOTS];
+    if (ovf == RT_WALK_ABORT) return fail(ctx, RT_ERR_DEVICE, "a traversal wave exceeded its step limit (internal error)");
+    overflowed = ovf != 0;
     if (ctx->profile_on) {
-      for (size_t s = 0; s < counts.size(); s++) {
-        uint64_t sum = 0;
-        for (uint32_t g = 0; g < NSEG; g++) sum += raw[s * CNT_SLAB + (size_t)g * RT_CSTRIDE];
-        counts[s] = (uint32_t)std::min<uint64_t>(sum, 0xffffffffu);
-      }
+      for (size_t s = 0; s < counts.size(); s++) counts[s] = sums[s];
       collect_profile(ctx, counts);
     }
-    auto seg_max = [&](int level, int kind) {
-      uint32_t m = 0;
-      for (uint32_t g = 0; g < NSEG; g++) m = std::max(m, raw[cnt_at(level, kind) + (size_t)g * RT_CSTRIDE]);
-      return (double)m;
-    };
+    auto seg_max = [&](int level, int kind) { return (double)maxs[level * CNT_KINDS + kind]; };
     double l0 = std::max(64.0, seg_max(0, CNT_Q));
     const int kinds[7] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ, CNT_MQ, CNT_MH, CNT_MS1};
     for (int k = 0; k < 7; k++)
