@@ -50,7 +50,7 @@ struct DInstance {      // a node that carries a primitive (64 bytes); its chain
   float wmin[3];        // padded world-space bounds (culling of mesh instances only)
   uint32_t has_uvw;     // mesh instances: the mesh has texture coordinates
   float wmax[3];
-  float pad2;
+  int32_t minst_k;      // mesh instances: position in DScene::minst / minst_rec
 };
 
 struct DMesh {
@@ -312,6 +312,81 @@ RT_DEV float wave_max(float v) {
 RT_DEV float wave_min(float v) { return v; }
 RT_DEV float wave_max(float v) { return v; }
 #endif
+
+// ---- segmented queues ------------------------------------------------------------------------------
+// One returning atomic on a single counter word saturates near 90 M/s on this chip, and a kernel that appends once
+// per wave per iteration is bound by exactly that.  Every queue is therefore split into nseg (64) segments with
+// their own length word (128 bytes apart): wave g appends to segment g % nseg, with ONE atomic per wave per append
+// site (ballot + mbcnt ranks), and consumer kernels give each wave one segment to walk.  Segments stay dense, the
+// contention per word drops 64x, and because children land in their parent's segment the worst-case length of a
+// segment is exactly (worst-case queue length) / nseg — no slack, no holes.
+#define RT_CSTRIDE 32u
+#define RT_NONE 0xFFFFFFFFu
+#ifndef RT_EMU
+#define RT_WAVE 64u
+RT_DEV uint32_t rt_lane() { return threadIdx.x & 63u; }
+RT_DEV uint32_t rt_wave_id() { return RT_TID >> 6; }
+RT_DEV uint32_t rt_num_waves() { return RT_NTHREADS >> 6; }
+RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0) return RT_NONE;
+  uint32_t n = (uint32_t)__popcll(mask);
+  uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)rt_lane() == leader) base = atomicAdd(counts + seg * RT_CSTRIDE, n);
+  base = (uint32_t)__shfl((int)base, leader);
+  if (!pred) return RT_NONE;
+  uint32_t pos = base + rank;
+  if (pos >= segcap) {
+    *overflow = 1u;
+    return RT_NONE;
+  }
+  return seg * segcap + pos;
+}
+#else
+#define RT_WAVE 1u
+RT_DEV uint32_t rt_lane() { return 0u; }
+RT_DEV uint32_t rt_wave_id() { return 0u; }
+RT_DEV uint32_t rt_num_waves() { return 1u; }
+RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
+  if (!pred) return RT_NONE;
+  uint32_t pos = counts[seg * RT_CSTRIDE]++;
+  if (pos >= segcap) {
+    *overflow = 1u;
+    return RT_NONE;
+  }
+  return seg * segcap + pos;
+}
+#endif
+
+// ---- candidates: what the first phase of the two-phase trace kernels hands to the second for every mesh instance a ray
+// still has to walk — the ray ALREADY IN THE INSTANCE'S SPACE (the first phase transforms it with scalar-loaded matrices, at
+// full lane occupancy, and has tested the instance's world box and the mesh's root box), so that entering an instance in the
+// persistent walk kernels is one 32-byte fetch instead of an instance loop with box tests and a chain of matrix fetches.
+// A ray's candidates form a linked list (each record names the ray's previous one).
+struct CandSink {
+  float4* rec;          // 2 float4 per candidate: (local origin, index into DScene::minst_rec) (local direction, next candidate)
+  uint32_t* count;      // length word of the segment this wave appends to
+  uint32_t base;        // index of the segment's first record
+  uint32_t segcap;
+  uint32_t* overflow;
+};
+// wave-uniform call sites (every lane of the wave calls): one atomic per wave
+RT_DEV uint32_t cand_push(const CandSink& K, bool pred) {
+  uint32_t at = seg_push(pred, K.count, 0u, K.segcap, K.overflow);
+  return at == RT_NONE ? RT_NONE : K.base + at;
+}
+// divergent call sites (the per-lane instance-BVH walk): one atomic per candidate
+RT_DEV uint32_t cand_alloc(const CandSink& K) {
+  uint32_t pos = rt_atomic_add_u32(K.count, 1u);
+  if (pos >= K.segcap) { *K.overflow = 1u; return RT_NONE; }
+  return K.base + pos;
+}
+RT_DEV void cand_write(const CandSink& K, uint32_t ci, V3 p, V3 d, uint32_t minst_k, uint32_t next) {
+  K.rec[2 * (size_t)ci] = make_float4(p.x, p.y, p.z, __uint_as_float(minst_k));
+  K.rec[2 * (size_t)ci + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(next));
+}
 
 // hitAABB, objects.cpp:94-120, returning also the entry parameter.  The ternaries keep FAST_MIN/FAST_MAX's
 // behaviour for NaN operands (0 * inf when a ray lies in a slab plane).
@@ -636,25 +711,42 @@ RT_DEV void best_init(Best& B) {
 // kernels: spheres and planes are tested, mesh instances are only culled against their world box and reported
 // through `mesh_flag` (their BVHs are walked by the second phase, k_trace_mesh).
 template <bool CNT, bool SPLIT>
-RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, bool& mesh_flag, uint32_t* stk, uint32_t stride,
-                              Cnt<CNT>& cnt) {
+RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, uint32_t& cand_head, const CandSink& K, uint32_t* stk,
+                              uint32_t stride, Cnt<CNT>& cnt, bool active = true) {
   V3 winv = v3(0, 0, 0);
   if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
+  RT_UTYPE(DMesh)* meshes = RT_UNIFORM_PTR(DMesh, S.meshes);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   ParentRay pr;
   pr.key = -2; pr.p = o; pr.d = dir;
-  mesh_flag = false;
-  float mesh_tmin = RT_BIG;  // nearest entry into a mesh instance's world box
+  cand_head = RT_NONE;
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     int prim = I->prim;
+    V3 p = o, d = dir;
     if (prim == 3) {  // world-bounds cull (the reference has none; a ray that misses the padded world box cannot
       float tm;       // hit the mesh, so the result is unchanged)
-      if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
-      if (SPLIT) { mesh_flag = true; mesh_tmin = tm < mesh_tmin ? tm : mesh_tmin; continue; }
+      bool want = box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm);
+      if (SPLIT) {
+        // first phase: the instance becomes a candidate of the second phase if the ray (a lane that has one) enters its
+        // world box not beyond the best hit so far and hits the mesh's root box in the instance's space — the tests
+        // TriObj::IntersectRay starts with (objects.cpp:172-183, 268-275), made here where the matrices are scalar loads
+        want = want && active && !(tm > prune_bound(B.t));
+        if (want) {
+          ray_to_instance(I, xf, o, dir, pr, p, d);
+          V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          RT_UTYPE(DMesh)* M = meshes + I->mesh;
+          cnt.node();
+          want = inv_is_finite(inv) ? box_test_fast(p, inv, M->bounds[0], M->bounds[1], M->bounds[2], M->bounds[3], M->bounds[4], M->bounds[5], tm)
+                                    : box_test(p, inv, M->bounds[0], M->bounds[1], M->bounds[2], M->bounds[3], M->bounds[4], M->bounds[5], tm);
+        }
+        uint32_t ci = cand_push(K, want);   // (every lane of the wave: the loop and this branch are wave-uniform)
+        if (ci != RT_NONE) { cand_write(K, ci, p, d, (uint32_t)I->minst_k, cand_head); cand_head = ci; }
+        continue;
+      }
+      if (!want) continue;
     }
-    V3 p, d;
     ray_to_instance(I, xf, o, dir, pr, p, d);
     cnt.inst();
     float t;
@@ -673,8 +765,6 @@ RT_DEV void closest_instances(const DScene& S, V3 o, V3 dir, int hitSide, Best& 
       }
     }
   }
-  // every mesh box is entered beyond the sphere / plane hit already found: no mesh can win, the second phase is skipped
-  if (SPLIT && mesh_flag && mesh_tmin > prune_bound(B.t)) mesh_flag = false;
 }
 
 // ---- instance BVH (TLAS).  RayTracer::TraverseTree tests every node of the scene graph for every ray
@@ -694,10 +784,10 @@ RT_DEV void ray_to_instance_full(IP I, const float* xfbase, V3 o, V3 dir, V3& p,
 }
 
 template <bool CNT, bool SPLIT>
-RT_DEV void closest_instances_tlas(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, bool& mesh_flag, uint32_t* stk, uint32_t stride,
-                                   Cnt<CNT>& cnt) {
+RT_DEV void closest_instances_tlas(const DScene& S, V3 o, V3 dir, int hitSide, Best& B, uint32_t& cand_head, const CandSink& K, uint32_t* stk,
+                                   uint32_t stride, Cnt<CNT>& cnt) {
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-  mesh_flag = false;
+  cand_head = RT_NONE;
   uint32_t cur = S.tlas_root;
   int sp = 0;
   for (;;) {
@@ -709,9 +799,20 @@ RT_DEV void closest_instances_tlas(const DScene& S, V3 o, V3 dir, int hitSide, B
         int prim = I->prim;
         float tm;
         if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
-        if (prim == 3 && SPLIT) { mesh_flag = true; continue; }
         V3 p, d;
         ray_to_instance_full(I, S.xf, o, dir, p, d);
+        if (prim == 3 && SPLIT) {   // a candidate of the second phase (see closest_instances); this walk is per lane
+          if (tm > prune_bound(B.t)) continue;
+          V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          const DMesh& M = S.meshes[I->mesh];
+          cnt.node();
+          bool hit = inv_is_finite(inv) ? box_test_fast(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)
+                                        : box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm);
+          if (!hit) continue;
+          uint32_t ci = cand_alloc(K);
+          if (ci != RT_NONE) { cand_write(K, ci, p, d, (uint32_t)I->minst_k, cand_head); cand_head = ci; }
+          continue;
+        }
         cnt.inst();
         float t;
         bool front;
@@ -760,9 +861,10 @@ RT_DEV void closest_instances_tlas(const DScene& S, V3 o, V3 dir, int hitSide, B
 }
 
 template <bool CNT, bool SPLIT>
-RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
+RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& cand_head, const CandSink& K, uint32_t* stk, uint32_t stride,
+                               Cnt<CNT>& cnt) {
   V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-  mesh_flag = false;
+  cand_head = RT_NONE;
   const float bound = prune_bound(t_max);
   uint32_t cur = S.tlas_root;
   int sp = 0;
@@ -776,9 +878,19 @@ RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, bool&
         float tm;
         if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
         if (prim == 3 && tm > prune_bound(t_max)) continue;  // the box begins beyond the light
-        if (prim == 3 && SPLIT) { mesh_flag = true; continue; }
         V3 p, d;
         ray_to_instance_full(I, S.xf, o, dir, p, d);
+        if (prim == 3 && SPLIT) {
+          V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          const DMesh& M = S.meshes[I->mesh];
+          cnt.node();
+          bool hit = inv_is_finite(inv) ? box_test_fast(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm)
+                                        : box_test(p, inv, M.bounds[0], M.bounds[1], M.bounds[2], M.bounds[3], M.bounds[4], M.bounds[5], tm);
+          if (!hit) continue;
+          uint32_t ci = cand_alloc(K);
+          if (ci != RT_NONE) { cand_write(K, ci, p, d, (uint32_t)I->minst_k, cand_head); cand_head = ci; }
+          continue;
+        }
         cnt.inst();
         bool occ = false;
         if (prim == 1) {
@@ -893,9 +1005,11 @@ template <bool CNT>
 RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   Best B;
   best_init(B);
-  bool mesh_flag;
-  if (S.use_tlas) closest_instances_tlas<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
-  else closest_instances<CNT, false>(S, o, dir, hitSide, B, mesh_flag, stk, stride, cnt);
+  uint32_t head;
+  CandSink none;
+  none.rec = nullptr; none.count = nullptr; none.base = 0; none.segcap = 0; none.overflow = nullptr;
+  if (S.use_tlas) closest_instances_tlas<CNT, false>(S, o, dir, hitSide, B, head, none, stk, stride, cnt);
+  else closest_instances<CNT, false>(S, o, dir, hitSide, B, head, none, stk, stride, cnt);
   return finalize_hit(S, o, dir, B, hit);
 }
 
@@ -903,16 +1017,17 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 // SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
 // `active`: this lane has a ray (the first-phase kernels call with every lane of the wave, see the wave-wide cull below).
 template <bool CNT, bool SPLIT>
-RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh_flag, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt,
-                          bool active = true) {
+RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& cand_head, const CandSink& K, uint32_t* stk, uint32_t stride,
+                          Cnt<CNT>& cnt, bool active = true) {
   V3 winv = v3(0, 0, 0);
   if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
+  RT_UTYPE(DMesh)* meshes = RT_UNIFORM_PTR(DMesh, S.meshes);
   ParentRay pr;
   pr.key = -2; pr.p = o; pr.d = dir;
   bool occluded = false;
-  mesh_flag = false;
+  cand_head = RT_NONE;
   // Box around the segments the WAVE's rays can be occluded on, [o, o + dir * t_max] (the rays of a wave are neighbours:
   // samples of the same few shadow groups).  An instance whose padded world box does not overlap it cannot occlude any
   // of them (an occluding point lies on a segment and inside the instance), so the whole wave skips its transform and
@@ -961,12 +1076,26 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
     int prim = I->prim;
     V3 p, d;
     ray_to_instance(I, xf, o, dir, pr, p, d);
+    if (prim == 3 && SPLIT) {   // [wave-uniform branch] a candidate of the second phase (see closest_instances)
+      float tm;
+      bool want = active && !occluded && box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm);
+      want = want && !(tm > prune_bound(t_max));   // the box begins beyond the light: nothing in it can occlude
+      if (want) {
+        V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        RT_UTYPE(DMesh)* M = meshes + I->mesh;
+        cnt.node();
+        want = inv_is_finite(inv) ? box_test_fast(p, inv, M->bounds[0], M->bounds[1], M->bounds[2], M->bounds[3], M->bounds[4], M->bounds[5], tm)
+                                  : box_test(p, inv, M->bounds[0], M->bounds[1], M->bounds[2], M->bounds[3], M->bounds[4], M->bounds[5], tm);
+      }
+      uint32_t ci = cand_push(K, want);
+      if (ci != RT_NONE) { cand_write(K, ci, p, d, (uint32_t)I->minst_k, cand_head); cand_head = ci; }
+      continue;
+    }
     if (occluded || !active) continue;  // lanes that already found an occluder idle; the loop itself stays wave-uniform
     if (prim == 3) {
       float tm;
       if (!box_test(o, winv, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2], tm)) continue;
       if (tm > prune_bound(t_max)) continue;  // the box begins beyond the light: nothing in it can occlude
-      if (SPLIT) { mesh_flag = true; continue; }
     }
     cnt.inst();
     if (prim == 1) {
@@ -984,9 +1113,11 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, bool& mesh
 }
 template <bool CNT>
 RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
-  bool mesh_flag;
-  if (S.use_tlas) return any_instances_tlas<CNT, false>(S, o, dir, t_max, mesh_flag, stk, stride, cnt);
-  return any_instances<CNT, false>(S, o, dir, t_max, mesh_flag, stk, stride, cnt);
+  uint32_t head;
+  CandSink none;
+  none.rec = nullptr; none.count = nullptr; none.base = 0; none.segcap = 0; none.overflow = nullptr;
+  if (S.use_tlas) return any_instances_tlas<CNT, false>(S, o, dir, t_max, head, none, stk, stride, cnt);
+  return any_instances<CNT, false>(S, o, dir, t_max, head, none, stk, stride, cnt);
 }
 
 // ------------------------------------------------------------------ second phase: per-lane walk over mesh instances
@@ -999,7 +1130,7 @@ struct MeshWalk {
   uint32_t pend;       // a leaf reached earlier and not yet intersected (0 = none), see k_trace_mesh
   uint32_t node_base, tri_base;
   int sp;
-  int mi;              // next entry of DScene::minst
+  uint32_t next;       // the ray's next candidate (RT_NONE: this is the last one)
   int inst;            // instance being walked
   bool fast;           // reciprocal direction finite: min3/max3 slab test (bit-identical decisions, see box_test_fast)
 };
@@ -1007,37 +1138,20 @@ struct MeshWalk {
 RT_DEV bool ref_is_node(uint32_t r) { return !(r & RT_LEAF); }                  // (RT_NOREF has the leaf bit)
 RT_DEV bool ref_is_leaf(uint32_t r) { return (r & RT_LEAF) && r != RT_NOREF; }
 
-// Advances to the next mesh instance whose padded world box and root box the ray hits; false when there is none left.
-// Same tests, in the same order, as closest_instances / any_instances make for a mesh instance.
+// Enters the mesh instance of candidate `ci`: the ray is already in the instance's space and is known to hit the mesh's
+// root box (first phase, closest_instances / any_instances); what is left is one 32-byte fetch and the walk's constants.
 template <bool CNT>
-RT_DEV bool mesh_walk_next(const DScene& S, V3 o, V3 dir, V3 winv, float t_limit, MeshWalk& W, Cnt<CNT>& cnt) {
-  while (W.mi < S.n_minst) {
-    const DMeshInst& R = S.minst_rec[W.mi++];
-    float tm;
-    if (!box_test(o, winv, R.wmin[0], R.wmin[1], R.wmin[2], R.wmax[0], R.wmax[1], R.wmax[2], tm)) continue;
-    if (tm > prune_bound(t_limit)) continue;  // entered beyond the best hit so far / the light: cannot matter
-    const float* chain = S.xf + R.xf_off;
-    V3 p = o, d = dir;
-    for (int k = 0; k < R.depth; k++) {
-      V3 np = xf_point(chain + 24 * k, p);
-      V3 nd = xf_dir(chain + 24 * k, d);
-      p = np; d = nd;
-    }
-    cnt.inst();
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    bool fast = inv_is_finite(inv);
-    cnt.node();
-    bool hit = fast ? box_test_fast(p, inv, R.bounds[0], R.bounds[1], R.bounds[2], R.bounds[3], R.bounds[4], R.bounds[5], tm)
-                    : box_test(p, inv, R.bounds[0], R.bounds[1], R.bounds[2], R.bounds[3], R.bounds[4], R.bounds[5], tm);
-    if (!hit) continue;
-    const int ii = R.inst;
-    const DMeshInst& M = R;
-    W.p = p; W.d = d; W.inv = inv; W.fast = fast;
-    W.cur = M.root_ref; W.pend = 0; W.sp = 0; W.inst = ii;
-    W.node_base = M.node_base; W.tri_base = M.tri_base;
-    return true;
-  }
-  return false;
+RT_DEV void mesh_walk_enter(const DScene& S, const float4* cand, uint32_t ci, MeshWalk& W, Cnt<CNT>& cnt) {
+  const float4 c0 = cand[2 * (size_t)ci], c1 = cand[2 * (size_t)ci + 1];
+  const DMeshInst& R = S.minst_rec[__float_as_uint(c0.w)];
+  cnt.inst();
+  W.p = v3(c0.x, c0.y, c0.z);
+  W.d = v3(c1.x, c1.y, c1.z);
+  W.inv = v3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
+  W.fast = inv_is_finite(W.inv);
+  W.next = __float_as_uint(c1.w);
+  W.cur = R.root_ref; W.pend = 0; W.sp = 0; W.inst = R.inst;
+  W.node_base = R.node_base; W.tri_base = R.tri_base;
 }
 
 // The 64-byte node record a walking lane stands at.  (A wave-cooperative variant — wanting lanes ranked, sixteen whole

@@ -54,13 +54,25 @@ struct GatherQ {  // photon-map lookups deferred to k_photon_gather (materials.c
 };
 
 struct MeshQ {       // work items of the second (mesh) phase of the trace kernels
-  uint4* item4;      // closest-hit: ray-queue entry, best t (bits), best instance, front flag
-  uint2* item2;      // shadow: group, sample index
+  uint4* item4;      // closest-hit: ray-queue entry, best t (bits), (best instance + 1) | front << 31, first candidate
+                     // shadow:      group, sample index, first candidate, ray length t_max (bits)
   uint32_t* counts;  // segment lengths
   uint32_t* cursor;  // per segment, RT_CSTRIDE words apart: next unclaimed item (claimed 1..64 at a time by the walkers)
   uint32_t segcap;
   uint32_t nseg;
+  float4* cand;           // candidates (CandSink, rt_device.h): the mesh instances of each item's ray, as a linked list
+  uint32_t* cand_counts;  // their segment lengths
+  uint32_t cand_segcap;
 };
+RT_DEV CandSink cand_sink(const MeshQ& MQ, uint32_t seg, uint32_t* overflow) {
+  CandSink K;
+  K.rec = MQ.cand;
+  K.count = MQ.cand_counts + seg * RT_CSTRIDE;
+  K.base = seg * MQ.cand_segcap;
+  K.segcap = MQ.cand_segcap;
+  K.overflow = overflow;
+  return K;
+}
 
 struct PassP {
   // camera constants, computed on the host exactly as RunThread does (RayTracer.cpp:95-101, 15-22)
@@ -95,53 +107,6 @@ struct FrameBufs {
   uint32_t* overflow;
   DCounters* counters;
 };
-
-// ---- segmented queues ------------------------------------------------------------------------------
-// One returning atomic on a single counter word saturates near 90 M/s on this chip, and a kernel that appends once
-// per wave per iteration is bound by exactly that.  Every queue is therefore split into nseg (64) segments with
-// their own length word (128 bytes apart): wave g appends to segment g % nseg, with ONE atomic per wave per append
-// site (ballot + mbcnt ranks), and consumer kernels give each wave one segment to walk.  Segments stay dense, the
-// contention per word drops 64x, and because children land in their parent's segment the worst-case length of a
-// segment is exactly (worst-case queue length) / nseg — no slack, no holes.
-#define RT_CSTRIDE 32u
-#define RT_NONE 0xFFFFFFFFu
-#ifndef RT_EMU
-#define RT_WAVE 64u
-RT_DEV uint32_t rt_lane() { return threadIdx.x & 63u; }
-RT_DEV uint32_t rt_wave_id() { return RT_TID >> 6; }
-RT_DEV uint32_t rt_num_waves() { return RT_NTHREADS >> 6; }
-RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
-  unsigned long long mask = __ballot(pred);
-  if (mask == 0) return RT_NONE;
-  uint32_t n = (uint32_t)__popcll(mask);
-  uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-  int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)rt_lane() == leader) base = atomicAdd(counts + seg * RT_CSTRIDE, n);
-  base = (uint32_t)__shfl((int)base, leader);
-  if (!pred) return RT_NONE;
-  uint32_t pos = base + rank;
-  if (pos >= segcap) {
-    *overflow = 1u;
-    return RT_NONE;
-  }
-  return seg * segcap + pos;
-}
-#else
-#define RT_WAVE 1u
-RT_DEV uint32_t rt_lane() { return 0u; }
-RT_DEV uint32_t rt_wave_id() { return 0u; }
-RT_DEV uint32_t rt_num_waves() { return 1u; }
-RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
-  if (!pred) return RT_NONE;
-  uint32_t pos = counts[seg * RT_CSTRIDE]++;
-  if (pos >= segcap) {
-    *overflow = 1u;
-    return RT_NONE;
-  }
-  return seg * segcap + pos;
-}
-#endif
 
 // Three appends to ONE segment of one queue with a single atomic (k_shade's refraction / reflection / indirect children):
 // pos[i] = entry index for append i or RT_NONE.  Every lane of the wave must call.
@@ -321,11 +286,11 @@ RT_KERNEL(k_raygen_trace, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ) {
     const uint32_t tile = idx / 64u;
     const uint32_t seg = tile % Q.nseg;
     const uint32_t qi = seg * Q.segcap + (tile / Q.nseg) * 64u + (idx % 64u);
-    bool need_mesh = false;
+    uint32_t head = RT_NONE;
     Best B;
     best_init(B);
+    V3 o = v3(0, 0, 0), dir = v3(1, 0, 0);
     if (valid) {
-      V3 o, dir;
       uint32_t pixel;
       int i;
       primary_ray(S, P, F, idx, o, dir, pixel, i);
@@ -337,15 +302,16 @@ RT_KERNEL(k_raygen_trace, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ) {
       Q.q3[qi] = m;
       F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       traced++;
-      // primary rays see front faces only (RayTracer.cpp:233)
-      if (TLAS) closest_instances_tlas<CNT, true>(S, o, dir, 1, B, need_mesh, stk, stride, cnt);
-      else closest_instances<CNT, true>(S, o, dir, 1, B, need_mesh, stk, stride, cnt);
-      if (!need_mesh) write_raw(Q, qi, B);
     }
-    uint32_t wi = seg_push(need_mesh, MQ.counts, seg % MQ.nseg, MQ.segcap, F.overflow);
+    // primary rays see front faces only (RayTracer.cpp:233)
+    const CandSink K = cand_sink(MQ, seg % MQ.nseg, F.overflow);
+    if (TLAS) { if (valid) closest_instances_tlas<CNT, true>(S, o, dir, 1, B, head, K, stk, stride, cnt); }
+    else closest_instances<CNT, true>(S, o, dir, 1, B, head, K, stk, stride, cnt, valid);   // (every lane: wave-wide appends)
+    if (valid && head == RT_NONE) write_raw(Q, qi, B);
+    uint32_t wi = seg_push(valid && head != RT_NONE, MQ.counts, seg % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
       uint4 it;
-      it.x = qi; it.y = __float_as_uint(B.t); it.z = (uint32_t)B.inst; it.w = B.front ? 1u : 0u;
+      it.x = qi; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
       MQ.item4[wi] = it;
     }
   }
@@ -371,25 +337,29 @@ RT_KERNEL(k_trace_closest, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ, int
   uint32_t traced = 0;
   RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
     uint32_t idx = seg_base_ + (uint32_t)seg_e;
-    bool need_mesh = false;
+    uint32_t head = RT_NONE;
     Best B;
     best_init(B);
+    V3 o = v3(0, 0, 0), dir = v3(1, 0, 0);
+    bool trace = false;
     if (seg_valid) {
       uint4 m = Q.q3[idx];
       if (!(m.w & (1u << 16))) {  // (re-shade entries carry a hit record written by k_shade, lights.cpp:172-183)
         float4 a = Q.q0[idx], b = Q.q1[idx];
-        V3 o = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z);
+        o = v3(a.x, a.y, a.z); dir = v3(b.x, b.y, b.z);
+        trace = true;
         traced++;
-        // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
-        if (TLAS) closest_instances_tlas<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
-        else closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, need_mesh, stk, stride, cnt);
-        if (!need_mesh) write_raw(Q, idx, B);
       }
     }
-    uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
+    // primary rays see front faces only (RayTracer.cpp:233), secondary rays both (lights.cpp:185)
+    const CandSink K = cand_sink(MQ, sw_.s % MQ.nseg, F.overflow);
+    if (TLAS) { if (trace) closest_instances_tlas<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, head, K, stk, stride, cnt); }
+    else closest_instances<CNT, true>(S, o, dir, level == 0 ? 1 : 3, B, head, K, stk, stride, cnt, trace);   // (every lane: wave-wide appends)
+    if (trace && head == RT_NONE) write_raw(Q, idx, B);
+    uint32_t wi = seg_push(trace && head != RT_NONE, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
       uint4 it;
-      it.x = idx; it.y = __float_as_uint(B.t); it.z = (uint32_t)B.inst; it.w = B.front ? 1u : 0u;
+      it.x = idx; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
       MQ.item4[wi] = it;
     }
   RT_SEG_END
@@ -480,7 +450,7 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
   best_init(B);
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
-  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
   MeshHit L;
   L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
   bool lfound = false;
@@ -513,15 +483,20 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
     const bool at_node = walking && ref_is_node(W.cur);
     const uint32_t n_walk = count_lanes(walking), n_node = count_lanes(at_node), n_pend = count_lanes(walking && W.pend != 0);
     // lanes that service can do something for (an idle lane only while unclaimed items may be left)
-    const uint32_t n_serv = count_lanes(state == RT_ST_DONE || state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
+    const uint32_t n_serv = count_lanes(state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
     if (n_walk == 0 && n_serv == 0) break;
     if (++guard > RT_WALK_GUARD) { *F.overflow = RT_WALK_ABORT; break; }
     if (n_serv >= refill_min || n_walk == 0) {
-      // ---- service: write finished rays, claim new items, enter the next mesh instance
+      // ---- service: a lane whose instance is walked takes its ray's next candidate or, after the last one, writes the
+      // ray's result and becomes idle; idle lanes claim new items and enter their first candidate.  One pass per candidate.
       WSTAT(2, 1); WSTAT(3, n_serv); WPHASE(13);
-      if (state == RT_ST_DONE) {
-        write_raw(Q, ray_idx, B);
-        state = RT_ST_IDLE;
+      uint32_t enter = RT_NONE;
+      if (state == RT_ST_NEXT) {
+        enter = W.next;
+        if (enter == RT_NONE) {
+          write_raw(Q, ray_idx, B);
+          state = RT_ST_IDLE;
+        }
       }
       if (segs_done < nseg) {
         bool exhausted;
@@ -530,25 +505,16 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
           uint4 it = MQ.item4[wi];
           ray_idx = it.x;
           best_init(B);
-          B.t = __uint_as_float(it.y); B.inst = (int)it.z; B.front = it.w != 0;
-          W.mi = 0;
+          B.t = __uint_as_float(it.y); B.inst = (int)(it.z & 0x7fffffffu) - 1; B.front = (it.z >> 31) != 0;
+          enter = it.w;   // (an item always has at least one candidate)
           n_items++;
-          state = RT_ST_NEXT;
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
-      if (state == RT_ST_NEXT) {
-        // the world-space ray is only needed here: it is re-read from the queue (once per instance entered) instead of
-        // being held in nine registers through the walk — the walk is latency-bound and gains from every wave more
-        float4 a = Q.q0[ray_idx], b = Q.q1[ray_idx];
-        V3 o = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z);
-        V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-        if (mesh_walk_next<CNT>(S, o, dir, winv, B.t, W, cnt)) {
-          L.t = RT_BIG; lfound = false;
-          state = RT_ST_WALK;
-        } else {
-          state = RT_ST_DONE;
-        }
+      if (enter != RT_NONE) {
+        mesh_walk_enter<CNT>(S, MQ.cand, enter, W, cnt);
+        L.t = RT_BIG; lfound = false;
+        state = RT_ST_WALK;
       }
       continue;
     }
@@ -1000,26 +966,27 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_hard, DScene S, PassP P, FrameBufs F, G
   uint32_t rays = 0;
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
-    bool need_mesh = false;
+    uint32_t head = RT_NONE;
     V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
     float tmax = 0.0f;
     if (seg_valid) {
       hard_shadow_ray(S, G.g0[g], Pp, d, tmax);
       rays++;
     }
+    const CandSink K = cand_sink(MQ, sw_.s % MQ.nseg, F.overflow);
     bool occ;
-    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt);
-    else occ = any_instances<CNT, true>(S, Pp, d, tmax, need_mesh, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull)
-    if (seg_valid) {
+    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, tmax, head, K, stk, stride, cnt);
+    else occ = any_instances<CNT, true>(S, Pp, d, tmax, head, K, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull and appends)
+    bool need_mesh = seg_valid && !occ && head != RT_NONE;
+    if (seg_valid && !occ && head == RT_NONE) {
       float4 g1 = G.g1[g];
-      if (occ) need_mesh = false;
-      else if (!need_mesh) add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+      add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
     }
     uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
-      uint2 it;
-      it.x = g; it.y = 0;
-      MQ.item2[wi] = it;
+      uint4 it;
+      it.x = g; it.y = 0; it.z = head; it.w = __float_as_uint(tmax);
+      MQ.item4[wi] = it;
     }
   RT_SEG_END
   if (CNT) {
@@ -1040,7 +1007,8 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
   const unsigned long long nj_magic = ((1ull << 40) + nj - 1u) / nj;   // ceil(2^40 / nj): e / nj == (e * magic) >> 40 for e < 2^32
   RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
     uint32_t g = RT_NONE, j = 0;
-    bool need_mesh = false, lit = false;
+    uint32_t head = RT_NONE;
+    bool lit = false;
     V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
     float dist = 0.0f;
     if (seg_valid) {
@@ -1054,19 +1022,18 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
       soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], G.g4[g], j, Pp, d, dist);
       rays++;
     }
+    const CandSink K = cand_sink(MQ, sw_.s % MQ.nseg, F.overflow);
     bool occ;
-    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt);
-    else occ = any_instances<CNT, true>(S, Pp, d, dist, need_mesh, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull)
-    if (seg_valid) {
-      if (occ) need_mesh = false;
-      else if (!need_mesh) lit = true;
-    }
+    if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, dist, head, K, stk, stride, cnt);
+    else occ = any_instances<CNT, true>(S, Pp, d, dist, head, K, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull and appends)
+    const bool need_mesh = seg_valid && !occ && head != RT_NONE;
+    if (seg_valid && !occ && head == RT_NONE) lit = true;
     run_count_add(lit, g, seg_valid ? (uint32_t*)&G.g2[g].z : nullptr);
     uint32_t wi = seg_push(need_mesh, MQ.counts, sw_.s % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
-      uint2 it;
-      it.x = g; it.y = j;
-      MQ.item2[wi] = it;
+      uint4 it;
+      it.x = g; it.y = j; it.z = head; it.w = __float_as_uint(dist);
+      MQ.item4[wi] = it;
     }
   RT_SEG_END
   if (CNT) {
@@ -1088,47 +1055,49 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   const uint32_t refill_min = RT_REFILL_MIN < RT_WAVE ? RT_REFILL_MIN : RT_WAVE;
   int state = RT_ST_IDLE;
   uint32_t group = 0;
-  V3 o = v3(0, 0, 0), dir = v3(0, 0, 0);
   float tmax = 0.0f;
   uint32_t guard = 0;
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
-  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.mi = 0; W.inst = -1; W.fast = true;
+  W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
   for (;;) {  // one wave-wide step per iteration, as in k_trace_mesh
     if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
     if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) state = RT_ST_NEXT;
     const bool walking = state == RT_ST_WALK;
     const bool at_node = walking && ref_is_node(W.cur);
     const uint32_t n_walk = count_lanes(walking), n_node = count_lanes(at_node), n_pend = count_lanes(walking && W.pend != 0);
-    const uint32_t n_serv = count_lanes(state == RT_ST_DONE || state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
+    const uint32_t n_serv = count_lanes(state == RT_ST_NEXT || (state == RT_ST_IDLE && segs_done < nseg));
     if (n_walk == 0 && n_serv == 0) break;
     if (++guard > RT_WALK_GUARD) { *F.overflow = RT_WALK_ABORT; break; }
     if (n_serv >= refill_min || n_walk == 0) {
-      if (state == RT_ST_DONE) {  // no mesh occludes the ray either: it is lit
-        if (SOFT) {
-          rt_atomic_add_u32((uint32_t*)&G.g2[group].z, 1u);
-        } else {
-          float4 g1 = G.g1[group];
-          add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+      // service: next candidate of the lane's ray, or — no mesh occludes it either — the ray is lit; then new items
+      uint32_t enter = RT_NONE;
+      if (state == RT_ST_NEXT) {
+        enter = W.next;
+        if (enter == RT_NONE) {
+          if (SOFT) {
+            rt_atomic_add_u32((uint32_t*)&G.g2[group].z, 1u);
+          } else {
+            float4 g1 = G.g1[group];
+            add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z));
+          }
+          state = RT_ST_IDLE;
         }
-        state = RT_ST_IDLE;
       }
       if (segs_done < nseg) {
         bool exhausted;
         uint32_t wi = claim_items(state == RT_ST_IDLE, MQ, seg, exhausted);
         if (wi != RT_NONE) {
-          uint2 it = MQ.item2[wi];
+          uint4 it = MQ.item4[wi];
           group = it.x;
-          if (SOFT) soft_shadow_ray(S, G.g0[group], G.g2[group], G.g3[group], G.g4[group], it.y, o, dir, tmax);
-          else hard_shadow_ray(S, G.g0[group], o, dir, tmax);
-          W.mi = 0;
-          state = RT_ST_NEXT;
+          enter = it.z;
+          tmax = __uint_as_float(it.w);   // (the ray itself is in the candidates, already in each instance's space)
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
-      if (state == RT_ST_NEXT) {
-        V3 winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-        state = mesh_walk_next<CNT>(S, o, dir, winv, tmax, W, cnt) ? RT_ST_WALK : RT_ST_DONE;
+      if (enter != RT_NONE) {
+        mesh_walk_enter<CNT>(S, MQ.cand, enter, W, cnt);
+        state = RT_ST_WALK;
       }
       continue;
     }

@@ -155,7 +155,7 @@ struct rt_context {
   DCounters* d_counters = nullptr;
   uint32_t path_budget = 0;
   // queue sizing: entries per camera sample in the fullest segment, by queue kind (measured by a pilot pass)
-  double fan[7] = {0, 0, 0, 0, 0, 0, 0};
+  double fan[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // see FramePlan::f
   size_t fan_key[10] = {0};
   bool fan_valid = false;
   std::vector<uint32_t> h_pixels;
@@ -646,11 +646,15 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     }
     D.has_uvw = has_uvw ? 1 : 0;
   }
-  for (DInstance& I : inst)
-    if (I.prim == RT_PRIM_MESH) {
-      I.shade_base = meshes[I.mesh].shade_base;
-      I.has_uvw = meshes[I.mesh].has_uvw;
-    }
+  {
+    int32_t mk = 0;
+    for (DInstance& I : inst)
+      if (I.prim == RT_PRIM_MESH) {
+        I.shade_base = meshes[I.mesh].shade_base;
+        I.has_uvw = meshes[I.mesh].has_uvw;
+        I.minst_k = mk++;   // position in DScene::minst / minst_rec (built below in the same order)
+      }
+  }
 
   // ---- materials, textures, lights
   std::vector<DMaterial> mtls;
@@ -834,7 +838,9 @@ enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4,
        CNT_MQ = 5, CNT_MH = 6, CNT_MS1 = 7, CNT_MS2 = 8,        // mesh-phase item queues: closest, hard shadow, soft shadow phases
        CUR_MQ = 9, CUR_MH = 10, CUR_MS1 = 11, CUR_MS2 = 12,     // their claim cursors
        CNT_GR = 13,                                             // photon lookups left to the second gather stage
-       CNT_KINDS = 14 };
+       CNT_CQ = 14, CNT_CH = 15, CNT_CS1 = 16, CNT_CS2 = 17,    // candidate lists of the mesh-phase items (MeshQ::cand)
+       CNT_KINDS = 18 };
+constexpr int NFAN = 10;
 constexpr int MAX_LEVELS = 8;
 constexpr uint32_t NSEG = 64;
 constexpr size_t CNT_SLAB = (size_t)NSEG * RT_CSTRIDE;                       // words per (level, kind)
@@ -1298,13 +1304,15 @@ struct FramePlan {
   int n_hard, n_soft; // light counts by shadow kind under these params
   bool photons;
   bool meshes;        // the scene has mesh instances: the second (mesh) phase of the trace kernels runs
-  double f[7];        // + f[4] closest-hit mesh items, f[5] hard-shadow mesh items, f[6] soft-shadow mesh items
+  double f[10];       // + f[4] closest-hit mesh items, f[5] hard-shadow mesh items, f[6] soft-shadow mesh items,
+                      //   f[7] / f[8] / f[9] their candidates (mesh instances per item's ray)
 };
 
 int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   size_t key[16] = {(size_t)fp.W, (size_t)fp.H, (size_t)fp.levels, (size_t)fp.branch, fp.budget, (size_t)fp.n_hard, (size_t)fp.n_soft,
                     (size_t)fp.photons, (size_t)(fp.f[0] * 4096), (size_t)(fp.f[1] * 4096), (size_t)(fp.f[2] * 4096), (size_t)(fp.f[3] * 4096),
-                    (size_t)(fp.f[4] * 4096), (size_t)(fp.f[5] * 4096), (size_t)(fp.f[6] * 4096), (size_t)fp.meshes};
+                    (size_t)(fp.f[4] * 4096) + ((size_t)(fp.f[7] * 4096) << 32), (size_t)(fp.f[5] * 4096) + ((size_t)(fp.f[8] * 4096) << 32),
+                    (size_t)(fp.f[6] * 4096) + ((size_t)(fp.f[9] * 4096) << 32), (size_t)fp.meshes};
   if (!ctx->frame_mem.empty() && !std::memcmp(key, ctx->frame_key, sizeof key)) return RT_OK;
   free_pool(ctx->frame_mem);
   std::memset(ctx->frame_key, 0, sizeof ctx->frame_key);
@@ -1364,20 +1372,24 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   ctx->GQ.counts = nullptr;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_retry = (uint32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_seed = (float*)p;
-  auto alloc_meshq = [&](MeshQ& q, double f, size_t item_bytes) {
+  auto alloc_meshq = [&](MeshQ& q, double f, double fc) {
     size_t sc = (fp.meshes && f > 0) ? cap_of(f) : 1;
+    size_t cc = (fp.meshes && f > 0) ? cap_of(std::max(f, fc)) : 1;
     q.segcap = (uint32_t)sc;
+    q.cand_segcap = (uint32_t)cc;
     q.nseg = NSEG;
-    q.counts = q.cursor = nullptr;
+    q.counts = q.cursor = q.cand_counts = nullptr;
     void* pp;
-    int r = alloc_dev(ctx, ctx->frame_mem, sc * NSEG * item_bytes, &pp);
+    int r = alloc_dev(ctx, ctx->frame_mem, sc * NSEG * 16, &pp);
     q.item4 = (uint4*)pp;
-    q.item2 = (uint2*)pp;
+    if (r) return r;
+    r = alloc_dev(ctx, ctx->frame_mem, cc * NSEG * 32, &pp);
+    q.cand = (float4*)pp;
     return r;
   };
-  if ((rc = alloc_meshq(ctx->MQ, fp.f[4], 16))) return rc;
-  if ((rc = alloc_meshq(ctx->MH, fp.n_hard ? fp.f[5] : 0.0, 8))) return rc;
-  if ((rc = alloc_meshq(ctx->MS, fp.n_soft ? fp.f[6] : 0.0, 8))) return rc;
+  if ((rc = alloc_meshq(ctx->MQ, fp.f[4], fp.f[7]))) return rc;
+  if ((rc = alloc_meshq(ctx->MH, fp.n_hard ? fp.f[5] : 0.0, fp.f[8]))) return rc;
+  if ((rc = alloc_meshq(ctx->MS, fp.n_soft ? fp.f[6] : 0.0, fp.f[9]))) return rc;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 16, &p))) return rc;
   ctx->d_path_rad = (float4*)p;
   size_t npx = (size_t)fp.W * fp.H;
@@ -1426,6 +1438,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     MeshQ q = base;
     q.counts = ctx->d_counts + cnt_at(lvl, kind_cnt);
     q.cursor = ctx->d_counts + cnt_at(lvl, kind_cur);
+    q.cand_counts = ctx->d_counts + cnt_at(lvl, kind_cnt == CNT_MQ ? CNT_CQ : (kind_cnt == CNT_MH ? CNT_CH : (kind_cnt == CNT_MS1 ? CNT_CS1 : CNT_CS2)));
     return q;
   };
   {  // camera rays + their first phase (instance table)
@@ -1584,10 +1597,13 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   const double worst = std::pow((double)fp.branch, fp.levels - 1);
   const bool meshes = ctx->n_minst > 0;
   const double soft_rays = std::max(RP.shadow_min, RP.shadow_max - RP.shadow_min);
-  const double fworst[7] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
-                            meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0};
+  const double nmi = std::max(1, ctx->n_minst);   // candidates per item: at most every mesh instance
+  const double fworst[NFAN] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
+                            meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0,
+                            meshes ? worst * nmi : 0.0, meshes ? worst * n_hard * nmi : 0.0, meshes ? worst * n_soft * soft_rays * nmi : 0.0};
   auto per_path_bytes = [&](const double* f) {
-    return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 84.0 * f[2] + 48.0 * f[3] + 16.0 * f[4] + 8.0 * f[5] + 8.0 * f[6] + 16.0 + 64.0;
+    return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 84.0 * f[2] + 48.0 * f[3] + 16.0 * (f[4] + f[5] + f[6]) +
+           32.0 * (std::max(f[4], f[7]) + std::max(f[5], f[8]) + std::max(f[6], f[9])) + 16.0 + 64.0;
   };
   // memory the frame resources (stage queues) may take: large passes amortise the per-launch tails of the
   // traversal kernels, and HBM is 288 GB
@@ -1604,11 +1620,11 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   if (ctx->fan_valid && std::memcmp(fkey, ctx->fan_key, sizeof fkey)) ctx->fan_valid = false;
   const bool need_pilot = !ctx->fan_valid && worst > 1.0;
   if (!need_pilot && !ctx->fan_valid) {  // no secondary rays at all: the worst case is exact
-    for (int k = 0; k < 7; k++) ctx->fan[k] = fworst[k];
+    for (int k = 0; k < NFAN; k++) ctx->fan[k] = fworst[k];
     std::memcpy(ctx->fan_key, fkey, sizeof fkey);
     ctx->fan_valid = true;
   }
-  for (int k = 0; k < 7; k++) fp.f[k] = need_pilot ? fworst[k] : ctx->fan[k];
+  for (int k = 0; k < NFAN; k++) fp.f[k] = need_pilot ? fworst[k] : ctx->fan[k];
   fp.meshes = meshes;
   uint32_t budget = need_pilot ? 131072u : budget_for(fp.f);
   fp.budget = budget;
@@ -1670,7 +1686,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
 
   constexpr uint32_t N_SLOTS = (MAX_LEVELS + 1) * CNT_KINDS;
   std::vector<uint32_t> counts(N_SLOTS);
-  double seen[7] = {0, 0, 0, 0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
+  double seen[NFAN] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // fullest-segment entries per camera sample, max over the passes of this call
   bool overflowed = false;
   auto finish_pass = [&](uint64_t paths) -> int {
     // the pass in 1 KB: per (level, kind) the sum and the maximum of the segment lengths + the overflow word, folded on the
@@ -1690,10 +1706,13 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     }
     auto seg_max = [&](int level, int kind) { return (double)maxs[level * CNT_KINDS + kind]; };
     double l0 = std::max(64.0, seg_max(0, CNT_Q));
-    const int kinds[7] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ, CNT_MQ, CNT_MH, CNT_MS1};
-    for (int k = 0; k < 7; k++)
+    const int kinds[NFAN] = {CNT_Q, CNT_GH, CNT_GS, CNT_GQ, CNT_MQ, CNT_MH, CNT_MS1, CNT_CQ, CNT_CH, CNT_CS1};
+    for (int k = 0; k < NFAN; k++)
       for (int l = (k == 0 ? 1 : 0); l <= fp.levels; l++) seen[k] = std::max(seen[k], seg_max(l, kinds[k]) / l0);
-    for (int l = 0; l <= fp.levels; l++) seen[6] = std::max(seen[6], seg_max(l, CNT_MS2) / l0);
+    for (int l = 0; l <= fp.levels; l++) {
+      seen[6] = std::max(seen[6], seg_max(l, CNT_MS2) / l0);
+      seen[9] = std::max(seen[9], seg_max(l, CNT_CS2) / l0);
+    }
     if (!overflowed && ctx->counters_on) ctx->host_paths += paths;  // paths = 0 for the sizing pass
     return RT_OK;
   };
@@ -1715,7 +1734,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     // A queue filled up: k_accumulate left the accumulator alone (it checks the flag).  Undo the work counters,
     // remember to size the queues larger from now on, and redo the pass in two halves.
     if (ctx->counters_on) HIP_TRY(hipMemcpy(ctx->d_counters, &saved_counters, sizeof saved_counters, hipMemcpyHostToDevice));
-    for (int k = 0; k < 7; k++) ctx->fan[k] = std::min(fworst[k], std::max(ctx->fan[k] * 2.0, seen[k] * 1.5));
+    for (int k = 0; k < NFAN; k++) ctx->fan[k] = std::min(fworst[k], std::max(ctx->fan[k] * 2.0, seen[k] * 1.5));
     if (discard) return RT_OK;
     if (ns > 1) {
       if ((r = pass(pixels, n_pix, sbase, ns / 2, false))) return r;
@@ -1746,10 +1765,10 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     if (overflowed) return fail(ctx, RT_ERR_OVERFLOW, "internal queue overflow in the sizing pass");
     double margin = 1.5;
     margin *= ctx->opt.fan_scale;  // tests: force the overflow / split path
-    for (int k = 0; k < 7; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
+    for (int k = 0; k < NFAN; k++) ctx->fan[k] = std::min(fworst[k], seen[k] * margin + (fworst[k] > 0 ? 0.03 : 0.0));
     std::memcpy(ctx->fan_key, fkey, sizeof fkey);
     ctx->fan_valid = true;
-    for (int k = 0; k < 7; k++) fp.f[k] = ctx->fan[k];
+    for (int k = 0; k < NFAN; k++) fp.f[k] = ctx->fan[k];
     budget = budget_for(fp.f);
     fp.budget = budget;
     if ((rc = ensure_frame(ctx, fp))) return rc;
