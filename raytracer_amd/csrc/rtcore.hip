@@ -63,6 +63,9 @@
 #ifndef RT_TLAS_MIN
 #define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
 #endif
+#ifndef RT_SOFT_CHUNK
+#define RT_SOFT_CHUNK 32   // soft-shadow samples per launch of the second sample phase when the scene has meshes (run_pass)
+#endif
 #ifndef RT_TRACE_BLOCKS_PER_CU
 #define RT_TRACE_BLOCKS_PER_CU 6   // traversal kernels: at most this many blocks per CU, fewer when the scene's stack needs the LDS
 #endif
@@ -1517,21 +1520,35 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       }
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
-        uint32_t nr = (uint32_t)(P.shadow_max - P.shadow_min);
-        {
-          Timer t(ctx, RT_K_SHADOW);
-          if (ctx->ds.use_tlas)
-            LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
-                     (uint32_t)P.shadow_min, nr, MS2);
-          else
-            LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2,
-                      (uint32_t)P.shadow_min, nr, MS2);
-          t.stop((uint64_t)(lvl * CNT_KINDS + CNT_N2));
-        }
-        if (meshes) {
-          Timer t(ctx, RT_K_SHADOW_MESH);
-          LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
-          t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS2));
+        // The remaining samples of the groups that are not fully lit (lights.cpp:56-59).  With meshes in the scene they are
+        // taken RT_SOFT_CHUNK samples at a time: every undecided ray is an item + candidates of the mesh phase (48 bytes),
+        // and 112 of them per group at once decided how many camera samples fit a pass (C5: 92 passes per step instead of 5).
+        // The shorter first chunk leaves a full-sized one for the pass summary's queue lengths.
+        const uint32_t nr_all = (uint32_t)(P.shadow_max - P.shadow_min);
+        const uint32_t chunk = meshes ? std::min<uint32_t>(nr_all, RT_SOFT_CHUNK) : nr_all;
+        uint32_t j0 = (uint32_t)P.shadow_min;
+        for (uint32_t done = 0; done < nr_all;) {
+          const uint32_t nr = (done == 0 && nr_all % chunk) ? nr_all % chunk : chunk;
+          if (done > 0) {   // the mesh phase's queues start empty again
+            HIP_TRY(hipMemsetAsync(ctx->d_counts + cnt_at(lvl, CNT_MS2), 0, CNT_SLAB * sizeof(uint32_t), ctx->stream));
+            HIP_TRY(hipMemsetAsync(ctx->d_counts + cnt_at(lvl, CUR_MS2), 0, CNT_SLAB * sizeof(uint32_t), ctx->stream));
+            HIP_TRY(hipMemsetAsync(ctx->d_counts + cnt_at(lvl, CNT_CS2), 0, CNT_SLAB * sizeof(uint32_t), ctx->stream));
+          }
+          {
+            Timer t(ctx, RT_K_SHADOW);
+            if (ctx->ds.use_tlas)
+              LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2, j0, nr, MS2);
+            else
+              LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2, j0, nr, MS2);
+            t.stop((uint64_t)(lvl * CNT_KINDS + CNT_N2));
+          }
+          if (meshes) {
+            Timer t(ctx, RT_K_SHADOW_MESH);
+            LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
+            t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS2));
+          }
+          j0 += nr;
+          done += nr;
         }
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
@@ -1596,7 +1613,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   fp.n_hard = n_hard; fp.n_soft = n_soft; fp.photons = photons_mixed;
   const double worst = std::pow((double)fp.branch, fp.levels - 1);
   const bool meshes = ctx->n_minst > 0;
-  const double soft_rays = std::max(RP.shadow_min, RP.shadow_max - RP.shadow_min);
+  const double soft_rays = std::max<int>(RP.shadow_min, std::min<int>(RP.shadow_max - RP.shadow_min, RT_SOFT_CHUNK));   // mesh-phase items of one launch
   const double nmi = std::max(1, ctx->n_minst);   // candidates per item: at most every mesh instance
   const double fworst[NFAN] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
                             meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0,

@@ -80,6 +80,10 @@ def test_stress_scene_scaled(emu):
     scene = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
     assert 45000 < scene.n_triangles() < 60000
     common_checks.check_stress_scene(emu, scene, 160, 90, n_rays=1500)
+    # soft shadows of the two sphere lights through the mesh phase: 16 samples, then the other 112 in chunks (run_pass)
+    p = params(48, 27, spp=1, jitter=1, bounces=1)
+    g, c = emu.Render(p), oracle_ffi.OracleScene(scene).render(p)
+    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
 
 
 def test_steady_state_calls_do_not_allocate(emu):
