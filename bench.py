@@ -63,16 +63,19 @@ class Config:
         return p
 
 
+HOST_BVH = True   # --device-bvh: meshes are handed over without a tree and rt_scene_commit builds it on the device
+
+
 def _load(path):
     def f():
         from raytracer_amd import Scene
-        return Scene.load(os.path.join(ROOT, path))
+        return Scene.load(os.path.join(ROOT, path), host_bvh=HOST_BVH)
     return f
 
 
 def _stress():
     from raytracer_amd import Scene
-    return Scene.stress(seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160)
+    return Scene.stress(seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160, host_bvh=HOST_BVH)
 
 
 def sphere_field_xml(n=2944, seed=11, width=1920, height=1080):
@@ -183,6 +186,8 @@ def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
     except AttributeError:
         nproc_affinity = nproc
     cores = int(os.environ.get("BENCH_CPU_THREADS", "0")) or min(16, nproc_affinity)
+    if not HOST_BVH:   # the oracle walks the trees the device built
+        scene = scene.with_bvh({i: renderer.GetMeshBVH(i) for i in range(scene.desc.n_meshes)})
     orc = oracle_ffi.OracleScene(scene)
     WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
     p = cfg.params(0)
@@ -234,13 +239,16 @@ def cpu_baseline(cfg, scene, renderer, target_seconds=12.0):
 
 
 def main():
+    global HOST_BVH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--device-bvh", action="store_true", help="mesh BVHs built at rt_scene_commit on the device instead of by the host loader")
     args = ap.parse_args()
+    HOST_BVH = not args.device_bvh
     cfg = CONFIGS[args.config]
     WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
 
@@ -366,20 +374,20 @@ def main():
                 + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
                 36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
                 / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
-                "k_raygen_trace"),
+                "k_raygen_trace<false"),
             "k_trace_mesh": (prof["trace_mesh"],
                              48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"],
                              36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"],
-                             "k_trace_mesh<false>"),
+                             "k_trace_mesh<false"),
             # 84 B per shade point in, 64 B per child ray, ~48 B per shadow group (32 hard / 80 soft; groups <= shade points x lights)
             "k_shade": (prof["shade"], 84.0 * cnt["shades"] + 64.0 * cnt["rays_secondary"]
                         + 48.0 * min(cnt["rays_shadow"], cnt["shades"] * scene.desc.n_lights) + 16.0 * cnt["tex_evals"],
-                        (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"], "k_shade<false>"),
+                        (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"], "k_shade<false"),
             # shadow rays, first phase (k_shadow_hard / k_shadow_soft): every instance test is charged here
             "k_shadow": (prof["shadow"], 48.0 * cnt["rays_shadow"],
                          36.0 * sh_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * cnt["rays_shadow"]
-                         / max(tc_rays + cnt["rays_shadow"], 1), "k_shadow_soft|k_shadow_hard"),
-            "k_shadow_mesh": (prof["shadow_mesh"], 32.0 * sh_nodes + 48.0 * sh_tris, 24.0 * sh_nodes + 51.0 * sh_tris, "k_shadow_mesh"),
+                         / max(tc_rays + cnt["rays_shadow"], 1), "k_shadow_soft<false|k_shadow_hard<false"),
+            "k_shadow_mesh": (prof["shadow_mesh"], 32.0 * sh_nodes + 48.0 * sh_tris, 24.0 * sh_nodes + 51.0 * sh_tris, "k_shadow_mesh<false"),
             "k_photon_gather": (prof["photon_gather"], 32.0 * cnt["photon_visits"] + 48.0 * cnt["gathers"], 20.0 * cnt["photon_visits"],
                                 "k_photon_gather"),
         }
@@ -397,7 +405,8 @@ def main():
                  "valu_algorithmic_frac": k_flops / lps / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                  "hbm_traffic_bytes_per_launch": None, "hbm_traffic_frac": None, "valu_issue_util": None,
                  "active_lane_ratio": None, "occupancy_waves_per_simd": None, "l2_hit_rate": None}
-            m = next(((pmc or {}).get(nm) for nm in pmc_name.split("|") if (pmc or {}).get(nm)), None)
+            m = next((v for nm in pmc_name.split("|") for k, v in sorted((pmc or {}).items())
+                      if isinstance(v, dict) and k.startswith(nm)), None)
             if m:   # counters of THIS build (the summary's kernel-source hash matches), per launch
                 if m.get("hbm_bytes_per_launch") is not None:
                     e["hbm_traffic_bytes_per_launch"] = m["hbm_bytes_per_launch"]
@@ -424,7 +433,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.workload}; {WIDTH}x{HEIGHT}, {SPP_PER_STEP} spp per GPU per step, Philox seed 1",
-                       "triangles": scene.n_triangles(), "scene_load_s": round(scene_load_s, 3), "scene_commit_s": round(scene_commit_s, 3),
+                       "triangles": scene.n_triangles(), "mesh_bvh": "binned SAH, host loader" if HOST_BVH else "linear BVH, built on the device at commit",
+                       "scene_load_s": round(scene_load_s, 3), "scene_commit_s": round(scene_commit_s, 3),
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
                        "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",

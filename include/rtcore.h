@@ -81,7 +81,8 @@ typedef struct rt_mesh {
   const uint32_t* nrm_idx;  /* 3 per face                     (cyTriMesh::FN) */
   const uint32_t* uvw_idx;  /* 3 per face, may be NULL => uvw (0,0,0)  (cyTriMesh::FT) */
   uint32_t n_positions, n_normals, n_uvw, n_faces;
-  const rt_bvh_node* bvh;   /* node 0 = root                  (BVHTriMesh, objects.h:65) */
+  const rt_bvh_node* bvh;   /* node 0 = root                  (BVHTriMesh, objects.h:65); NULL (with n_bvh_nodes = 0):
+                             * rt_scene_commit builds the tree on the device (linear BVH, leaves <= 4) */
   const uint32_t* bvh_elements; /* face ids, grouped per leaf */
   uint32_t n_bvh_nodes, n_bvh_elements;
   float bound_min[3], bound_max[3]; /* cyTriMesh::GetBoundMin/Max (objects.h:57) */
@@ -260,6 +261,14 @@ const char* rt_last_error(const rt_context* ctx);
 /* Replaces the in-memory hand-over at the end of Renderer::LoadScene (xmlload.cpp:70-72):
  * the flattened scene is copied to the device, instance chains and acceleration data are built. */
 int rt_scene_commit(rt_context* ctx, const rt_scene_desc* scene);
+
+/* The BVH of mesh `mesh_id` of the committed scene in rt_mesh form (nodes in depth-first pre-order, node 0 = root;
+ * per-leaf face lists): the tree the mesh came with, or the one rt_scene_commit built on the device for a mesh
+ * without one (reference: BVHTriMesh inside TriObj::Load, RayTracer/objects.h:60-67).  `n_nodes` / `n_elements`
+ * always receive the sizes; the arrays are filled when both capacities suffice (RT_ERR_INVALID otherwise, unless
+ * `nodes` is NULL = size query). */
+int rt_scene_mesh_bvh(rt_context* ctx, int mesh_id, rt_bvh_node* nodes, uint32_t node_cap, uint32_t* elements,
+                      uint32_t elem_cap, uint32_t* n_nodes, uint32_t* n_elements);
 
 /* Batched Renderer::TraceRay (RayTracer.cpp:336-339 -> TraverseTree :373-435). Host pointers. */
 int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side, rt_hit* hits);

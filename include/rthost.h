@@ -41,6 +41,11 @@ const char* rth_scene_node_name(const rth_scene* s, int node);
 /* Number of warnings the loader printed (unknown tags, missing assets...). */
 int rth_scene_warnings(const rth_scene* s);
 
+/* Process-wide switch for the scenes loaded or generated afterwards: 1 (default) = every mesh gets its BVH here
+ * (binned SAH, as TriObj::Load builds one on load, objects.h:65); 0 = meshes are handed over without a tree
+ * (rt_mesh::bvh == NULL) and rt_scene_commit builds a linear BVH on the device. */
+void rth_set_host_bvh(int on);
+
 /* Synthetic stress scene (BASELINE config 5): n_instances icospheres of 20*4^subdiv triangles
  * baked into ONE world-space mesh plus a displaced ground grid, two sphere lights. */
 rth_scene* rth_scene_generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height);

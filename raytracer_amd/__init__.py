@@ -22,6 +22,7 @@ __all__ = ["Scene", "Renderer", "RenderImage", "default_params", "rays_from_arra
 RAY_DTYPE = np.dtype([("p", np.float32, 3), ("dir", np.float32, 3)])
 HIT_DTYPE = np.dtype([("p", np.float32, 3), ("z", np.float32), ("N", np.float32, 3), ("uvw", np.float32, 3),
                       ("node", np.int32), ("face", np.int32), ("light", np.int32), ("front", np.int32)])
+BVH_NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("a", np.uint32), ("bmax", np.float32, 3), ("b", np.uint32)])
 PHOTON_DTYPE = np.dtype([("position", np.float32, 3), ("power", np.float32), ("dir", np.float32, 3),
                          ("color", np.uint8, 3), ("plane", np.uint8)])
 assert RAY_DTYPE.itemsize == C.sizeof(rt_ray) and HIT_DTYPE.itemsize == C.sizeof(rt_hit)
@@ -51,20 +52,38 @@ class Scene:
         self.desc_ptr = self._host.rth_scene_desc(self._h)
         self.desc = self.desc_ptr.contents
 
+    # host_bvh=False: the meshes come without a tree and Renderer.LoadScene (rt_scene_commit) builds it on the device
     @classmethod
-    def load(cls, path, asset_dir=None):
+    def load(cls, path, asset_dir=None, host_bvh=True):
         host = _ffi.load_host()
-        return cls(host.rth_scene_load_file(os.fsencode(path), os.fsencode(asset_dir) if asset_dir else None))
+        host.rth_set_host_bvh(1 if host_bvh else 0)
+        try:
+            return cls(host.rth_scene_load_file(os.fsencode(path), os.fsencode(asset_dir) if asset_dir else None))
+        finally:
+            host.rth_set_host_bvh(1)
 
     @classmethod
-    def from_string(cls, xml, asset_dir=None):
+    def from_string(cls, xml, asset_dir=None, host_bvh=True):
         host = _ffi.load_host()
-        return cls(host.rth_scene_load_string(xml.encode(), os.fsencode(asset_dir) if asset_dir else None))
+        host.rth_set_host_bvh(1 if host_bvh else 0)
+        try:
+            return cls(host.rth_scene_load_string(xml.encode(), os.fsencode(asset_dir) if asset_dir else None))
+        finally:
+            host.rth_set_host_bvh(1)
 
     @classmethod
-    def stress(cls, seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160):
+    def stress(cls, seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160, host_bvh=True):
         host = _ffi.load_host()
-        return cls(host.rth_scene_generate_stress(seed, n_instances, subdiv, ground_res, width, height))
+        host.rth_set_host_bvh(1 if host_bvh else 0)
+        try:
+            return cls(host.rth_scene_generate_stress(seed, n_instances, subdiv, ground_res, width, height))
+        finally:
+            host.rth_set_host_bvh(1)
+
+    def with_bvh(self, trees):
+        """A view of this scene whose meshes carry other trees: `trees[mesh_id]` = (nodes, elements) as
+        Renderer.GetMeshBVH returns them, or None for "no tree, build it on the device"."""
+        return _SceneView(self, trees)
 
     @property
     def warnings(self):
@@ -92,6 +111,50 @@ class Scene:
                 self._h = None
         except Exception:
             pass
+
+
+class _SceneView:
+    """Scene.with_bvh: the parent's flattened scene with the BVH fields of some meshes replaced (host memory of both is
+    kept alive by this object)."""
+
+    def __init__(self, parent, trees):
+        self._parent = parent
+        self._host = parent._host
+        self._keep = []
+        n = parent.desc.n_meshes
+        self._meshes = (_ffi.rt_mesh * max(n, 1))()
+        for i in range(n):
+            C.memmove(C.byref(self._meshes[i]), C.byref(parent.desc.meshes[i]), C.sizeof(_ffi.rt_mesh))
+            if i in trees:
+                m = self._meshes[i]
+                if trees[i] is None:
+                    m.bvh = None
+                    m.bvh_elements = None
+                    m.n_bvh_nodes = m.n_bvh_elements = 0
+                else:
+                    nodes = np.ascontiguousarray(trees[i][0], dtype=BVH_NODE_DTYPE)
+                    elems = np.ascontiguousarray(trees[i][1], dtype=np.uint32)
+                    self._keep += [nodes, elems]
+                    m.bvh = C.cast(nodes.ctypes.data, C.POINTER(_ffi.rt_bvh_node))
+                    m.bvh_elements = C.cast(elems.ctypes.data, C.POINTER(C.c_uint32))
+                    m.n_bvh_nodes, m.n_bvh_elements = len(nodes), len(elems)
+        self.desc = rt_scene_desc()
+        C.memmove(C.byref(self.desc), C.byref(parent.desc), C.sizeof(rt_scene_desc))
+        self.desc.meshes = C.cast(self._meshes, C.POINTER(_ffi.rt_mesh))
+        self.desc_ptr = C.pointer(self.desc)
+
+    width = property(lambda self: self.desc.camera.width)
+    height = property(lambda self: self.desc.camera.height)
+    warnings = property(lambda self: self._parent.warnings)
+
+    def node_name(self, i):
+        return self._parent.node_name(i)
+
+    def n_triangles(self):
+        return self._parent.n_triangles()
+
+    def with_bvh(self, trees):
+        return _SceneView(self, trees)
 
 
 class RenderImage:
@@ -149,9 +212,20 @@ class Renderer:
 
     # -- reference API -----------------------------------------------------------------
     def LoadScene(self, path_or_scene, asset_dir=None):
-        self.scene = path_or_scene if isinstance(path_or_scene, Scene) else Scene.load(path_or_scene, asset_dir)
+        self.scene = path_or_scene if isinstance(path_or_scene, (Scene, _SceneView)) else Scene.load(path_or_scene, asset_dir)
         self._check(self._lib.rt_scene_commit(self._ctx, self.scene.desc_ptr), "rt_scene_commit")
         return True
+
+    def GetMeshBVH(self, mesh_id):
+        """(nodes, elements) of a committed mesh's BVH in rt_mesh form — the tree it came with or the one built on the
+        device for a mesh without one (reference: BVHTriMesh, RayTracer/objects.h:60-67)."""
+        nn, ne = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.rt_scene_mesh_bvh(self._ctx, mesh_id, None, 0, None, 0, C.byref(nn), C.byref(ne)), "rt_scene_mesh_bvh")
+        nodes = np.zeros(nn.value, dtype=BVH_NODE_DTYPE)
+        elems = np.zeros(ne.value, dtype=np.uint32)
+        self._check(self._lib.rt_scene_mesh_bvh(self._ctx, mesh_id, nodes.ctypes.data, nn.value, elems.ctypes.data, ne.value,
+                                                C.byref(nn), C.byref(ne)), "rt_scene_mesh_bvh")
+        return nodes, elems
 
     def _dims(self, params):
         w = params.width if params.width > 0 else self.scene.width

@@ -185,6 +185,8 @@ def load_host():
     lib.rth_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.rth_read_image_rgb.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rth_free.argtypes = [C.c_void_p]
+    lib.rth_set_host_bvh.argtypes = [C.c_int]
+    lib.rth_set_host_bvh.restype = None
     _host = lib
     return lib
 
@@ -195,11 +197,12 @@ CORE_SYMBOLS = [
     "rt_photons_build", "rt_photons_download", "rt_photons_set", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
     "rt_counters_reset", "rt_counters_get", "rt_profile_enable", "rt_profile_reset", "rt_profile_get",
     "rt_render_params_default", "rt_set_option", "rt_debug_alloc_count", "rt_denoise_noalloc", "rt_photons_download_tree", "rt_reduce_accumulators",
+    "rt_scene_mesh_bvh",
 ]
 HOST_SYMBOLS = [
     "rth_scene_load_file", "rth_scene_load_string", "rth_scene_free", "rth_last_error", "rth_scene_desc",
     "rth_scene_node_name", "rth_scene_warnings", "rth_scene_generate_stress", "rth_write_png", "rth_read_image_rgb",
-    "rth_free",
+    "rth_free", "rth_set_host_bvh",
 ]
 
 
@@ -258,6 +261,7 @@ def bind_core(lib):
     lib.rt_photons_build.argtypes = [vp, C.POINTER(rt_render_params)]
     lib.rt_photons_download.argtypes = [vp, C.c_int, vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.rt_photons_download_tree.argtypes = [vp, C.c_int, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rt_scene_mesh_bvh.argtypes = [vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.rt_photons_set.argtypes = [vp, C.c_int, vp, C.c_int32]
     lib.rt_photon_gather.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_int, vp]
     lib.rt_denoise.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp]

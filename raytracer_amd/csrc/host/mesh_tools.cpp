@@ -63,8 +63,8 @@ void HostMesh::fill(rt_mesh& o) const {
   o.n_normals = (uint32_t)(nrm.size() / 3);
   o.n_uvw = (uint32_t)(uvw.size() / 3);
   o.n_faces = n_faces();
-  o.bvh = bvh.data();
-  o.bvh_elements = elems.data();
+  o.bvh = bvh.empty() ? nullptr : bvh.data();   // empty: rth_set_host_bvh(0), the renderer core builds the tree
+  o.bvh_elements = elems.empty() ? nullptr : elems.data();
   o.n_bvh_nodes = (uint32_t)bvh.size();
   o.n_bvh_elements = (uint32_t)elems.size();
   for (int k = 0; k < 3; k++) { o.bound_min[k] = bmin[k]; o.bound_max[k] = bmax[k]; }
@@ -233,10 +233,14 @@ struct Builder {
 
 }  // namespace
 
+static std::atomic<int> g_host_bvh{1};
+void set_host_bvh(int on) { g_host_bvh = on ? 1 : 0; }
+
 void HostMesh::build_bvh(int max_leaf, int max_depth) {
   bvh.clear();
   elems.clear();
   bvh_depth = 0;
+  if (!g_host_bvh) return;   // rt_scene_commit builds the tree on the device (rt_mesh::bvh == NULL)
   if (n_faces() == 0) {
     rt_bvh_node n;
     std::memset(&n, 0, sizeof n);

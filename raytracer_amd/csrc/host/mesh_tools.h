@@ -35,6 +35,9 @@ struct HostMesh {
   void fill(rt_mesh& out) const;
 };
 
+// 0: meshes are handed over without a tree (rt_mesh::bvh == NULL) and the renderer core builds it on the device
+void set_host_bvh(int on);
+
 // Wavefront OBJ subset: v / vt / vn / f (polygons fan-triangulated, negative indices), mtllib/usemtl.
 bool load_obj(const std::string& path, HostMesh& mesh, std::string& err);
 

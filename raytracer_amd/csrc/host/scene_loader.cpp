@@ -495,6 +495,7 @@ const char* rth_scene_node_name(const rth_scene* s, int node) {
   return s->node_names[node].c_str();
 }
 int rth_scene_warnings(const rth_scene* s) { return s ? s->warnings : 0; }
+void rth_set_host_bvh(int on) { set_host_bvh(on); }
 
 // BASELINE config 5 stand-in: instanced icospheres baked into one world-space mesh + displaced ground.
 rth_scene* rth_scene_generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height) {

@@ -654,12 +654,23 @@ RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs,
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4   // measured on the C2 bench: 2 -> 7.37 ms, 3 -> 6.52 ms, 4 -> 6.26 ms per step
 #endif
+#ifdef RT_SHADE_STATS   // developer build: wave cycles per region of k_shade
+__device__ unsigned long long g_shade_stats[16];
+#define SPHASE(ph) do { long long tn_ = clock64(); if (rt_lane() == 0) ss[sphase] += (unsigned long long)(tn_ - stprev); stprev = tn_; sphase = (ph); } while (0)
+#else
+#define SPHASE(ph) do { } while (0)
+#endif
 template <bool CNT, bool MC, bool PH>
 RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
   RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);
+#ifdef RT_SHADE_STATS
+  unsigned long long ss[16] = {0};
+  long long stprev = clock64(); int sphase = 0;
+#endif
   RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
+    SPHASE(1);
     const uint32_t oseg = sw_.s % QN.nseg;  // children and shadow work stay in the parent's segment
     uint32_t idx = seg_base_ + (uint32_t)seg_e;
     bool valid = seg_valid;
@@ -694,6 +705,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         h1 = Q.h1[idx];
         h2 = Q.h2[idx];
       } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
+        SPHASE(2);
         Best B;
         read_raw(Q, idx, B);
         Hit h;
@@ -706,6 +718,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           F.hit_face[pixel] = h.light >= 0 ? -1 : h.face;
         }
       }
+      SPHASE(3);
       w = v3(q0.w, q1.w, q2.w);
       V3 pabs = v3(q2.x, q2.y, q2.z);
       V3 rdir = v3(q1.x, q1.y, q1.z);
@@ -754,6 +767,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           add_radiance(F, slot, w);
         } else {
           surface = true;
+          SPHASE(4);
           // materials.cpp:231-236
           // (one copy of the texture code in a loop that is not unrolled, results routed by selects, was measured: the
           // kernel shrinks by a third and runs 5 % SLOWER on C2 — the six inlined copies stay)
@@ -775,6 +789,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           bool have_r0 = false, have_r1 = false;
           float mior = M.ior, mgloss = M.glossiness.v;
 
+          SPHASE(5);
           if (mior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
             float iorRatio = (1.0f - mior) / (1.0f + mior);
             V3 fresnel = refraction * (iorRatio * iorRatio);
@@ -789,6 +804,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
               p_refr = true;
             }
           }
+          SPHASE(6);
           if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
             V3 wc = w * reflection;
             if (nonzero(wc)) {
@@ -801,6 +817,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
               p_refl = true;
             }
           }
+          SPHASE(7);
           V3 local = emission;
           if (MC && P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
             V3 wc = w * kd;
@@ -829,6 +846,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
       }
     }
 
+    SPHASE(8);
     if (aov) {
       F.aov_depth[pixel] = aov_z;
       F.aov_normal[3 * (size_t)pixel] = aov_n.x; F.aov_normal[3 * (size_t)pixel + 1] = aov_n.y; F.aov_normal[3 * (size_t)pixel + 2] = aov_n.z;
@@ -850,6 +868,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
       if (MC && cpos[2] != RT_NONE) write_child(QN, cpos[2], c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
     }
 
+    SPHASE(9);
     // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
     for (int li = 0; li < S.n_lights; li++) {
       RT_UTYPE(DLight)* L = lights + li;
@@ -900,6 +919,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         }
       }
     }
+    SPHASE(10);
     if (PH && P.photons) {
       uint32_t gi = seg_push(p_gather, GQ.counts, oseg, GQ.segcap, F.overflow);
       if (gi != RT_NONE) {
@@ -908,7 +928,12 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
       }
     }
+    SPHASE(0);
   RT_SEG_END
+#ifdef RT_SHADE_STATS
+  SPHASE(0);
+  if (rt_lane() == 0) for (int i = 0; i < 16; i++) if (ss[i]) atomicAdd(&g_shade_stats[i], ss[i]);
+#endif
   if (CNT) {
     cnt.flush(F.counters);
     if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);

@@ -5,6 +5,7 @@
 #include "rt_kernels.h"
 #include "rt_photon.h"
 #include "rt_photon_build.h"
+#include "rt_bvh_build.h"
 #include "rt_denoise.h"
 
 #include <algorithm>
@@ -85,6 +86,8 @@ struct DevMem {
 template <class T>
 T* dptr(const DevMem& m) { return (T*)m.p; }
 
+struct MeshInfo { uint32_t n_nodes = 0, n_slots = 0; };   // inner nodes and triangle slots a committed mesh uses
+
 }  // namespace
 
 // ---- rt_denoise_noalloc: the filter's working images in a fixed device array instead of allocated buffers.
@@ -134,6 +137,8 @@ struct rt_context {
   int n_nodes = 0, n_hard_lights = 0, n_soft_capable = 0, n_gloss = 0, n_minst = 0;
   std::vector<rt_light> lights;
   std::vector<DInstance> h_inst;
+  std::vector<DMesh> h_meshes;      // as committed (rt_scene_mesh_bvh)
+  std::vector<MeshInfo> h_minfo;
   std::vector<rt_material> h_materials;
 
   // frame resources
@@ -398,6 +403,123 @@ int fail(rt_context* ctx, int code, const std::string& msg) {
   return code;
 }
 
+// One slab of device memory cut into 256-byte aligned pieces.
+struct Carver {
+  unsigned char* base = nullptr;
+  size_t used = 0;
+  template <class T>
+  T* take(size_t count) {
+    T* p = base ? (T*)(base + used) : nullptr;
+    used += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+
+// stable sort of (key, value) pairs on bits [0, end_bit) of the key
+int sort_pairs(rt_context* ctx, void* tmp, size_t tmp_bytes, const unsigned long long* kin, unsigned long long* kout, const uint32_t* vin,
+               uint32_t* vout, size_t n, int end_bit) {
+#ifndef RT_EMU
+  if (rt_sort_pairs_u64(tmp, &tmp_bytes, kin, kout, vin, vout, n, end_bit, (void*)ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "device sort failed");
+#else
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+  const unsigned long long mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (kin[a] & mask) < (kin[b] & mask); });
+  for (size_t i = 0; i < n; i++) { kout[i] = kin[order[i]]; vout[i] = vin[order[i]]; }
+#endif
+  return RT_OK;
+}
+
+
+// BVH of a mesh that came without one, built on the device into its ranges of the node / slot arrays (rt_bvh_build.h).
+// `depth` = depth of the deepest leaf (root = 0), as MeshConv::max_depth.
+int lbvh_build(rt_context* ctx, const rt_mesh& m, float4* nodes, float4* tris, DMesh& D, MeshInfo& info, int& depth) {
+  const uint32_t n = m.n_faces;
+  depth = 0;
+  info.n_nodes = 0; info.n_slots = n;
+  D.root_ref = RT_LEAF;
+  for (int k = 0; k < 6; k++) D.bounds[k] = 0.0f;
+  if (n == 0) return RT_OK;
+  const int max_levels = RT_STACK - 4;   // inner nodes on levels 0 .. 27, leaves no deeper than 28
+  size_t sort_tmp = 0;
+#ifndef RT_EMU
+  if (rt_sort_pairs_u64(nullptr, &sort_tmp, nullptr, nullptr, nullptr, nullptr, n, 63, nullptr) != 0) return fail(ctx, RT_ERR_DEVICE, "device sort sizing failed");
+#endif
+  Carver cv;
+  float *pos = nullptr, *out = nullptr;
+  uint32_t *fidx = nullptr, *vals_in = nullptr, *vals_out = nullptr, *total = nullptr;
+  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+  float4* pbox = nullptr;
+  uint2 *work = nullptr, *lv = nullptr;
+  uint8_t* tmp = nullptr;
+  DevMem slab;
+  for (int pass = 0; pass < 2; pass++) {
+    cv.used = 0;
+    pos = cv.take<float>(3 * (size_t)m.n_positions); fidx = cv.take<uint32_t>(3 * (size_t)n);
+    keys_in = cv.take<unsigned long long>(n); keys_out = cv.take<unsigned long long>(n);
+    vals_in = cv.take<uint32_t>(n); vals_out = cv.take<uint32_t>(n);
+    pbox = cv.take<float4>(2 * (size_t)n);
+    work = cv.take<uint2>(n);
+    lv = cv.take<uint2>(max_levels + 2);
+    total = cv.take<uint32_t>(4);
+    out = cv.take<float>(8);
+    tmp = cv.take<uint8_t>(sort_tmp + 16);
+    if (pass == 0) {
+      HIP_TRY(hipMalloc(&slab.p, cv.used));
+      ctx->n_allocs++;
+      cv.base = (unsigned char*)slab.p;
+    }
+  }
+  struct Release { DevMem& m; ~Release() { m.release(); } } release{slab};
+  HIP_TRY(hipMemcpyAsync(pos, m.positions, 3 * (size_t)m.n_positions * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(fidx, m.pos_idx, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  LbvhArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.pos = pos; A.fidx = fidx; A.n = n;
+  for (int k = 0; k < 3; k++) {
+    const float ext = m.bound_max[k] - m.bound_min[k];
+    A.lo[k] = m.bound_min[k];
+    A.scale[k] = ext > 0.0f ? 2097152.0f / ext : 0.0f;
+  }
+  A.keys = keys_in; A.vals = vals_in; A.tris = tris; A.nodes = nodes; A.pbox = pbox; A.work = work; A.lv = lv; A.total = total;
+  A.max_levels = max_levels;
+  LAUNCH(k_lbvh_keys, n, A);
+  int rc = sort_pairs(ctx, tmp, sort_tmp, keys_in, keys_out, vals_in, vals_out, n, 63);
+  if (rc) return rc;
+  A.keys = keys_out; A.vals = vals_out;
+  LAUNCH(k_lbvh_slots, n, A);
+  std::vector<uint2> h_lv(max_levels + 1);
+  for (auto& l : h_lv) l.x = l.y = 0;
+  uint32_t root_ref = RT_LEAF | n;
+  if (n > 4) {
+    root_ref = 0;
+    const uint2 root_run = [&] { uint2 r; r.x = 0; r.y = n; return r; }();
+    const uint2 lv0 = [&] { uint2 r; r.x = 0; r.y = 1; return r; }();
+    const uint32_t one = 1;
+    HIP_TRY(hipMemcpyAsync(work, &root_run, sizeof root_run, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(lv, &lv0, sizeof lv0, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(total, &one, sizeof one, hipMemcpyHostToDevice, ctx->stream));
+    for (int level = 0; level < max_levels; level++) {
+      const unsigned long long most = std::min<unsigned long long>(1ull << level, (unsigned long long)n / 5 + 1);
+      LAUNCH(k_lbvh_split, most, A, level);
+      LAUNCH(k_lbvh_next, 1, A, level);
+    }
+    HIP_TRY(hipMemcpyAsync(h_lv.data(), lv, h_lv.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_lv[max_levels].y != 0) return fail(ctx, RT_ERR_DEVICE, "device BVH build ran out of levels");
+    for (int level = 0; level < max_levels && h_lv[level].y; level++) depth = level + 1;
+    for (int level = depth - 1; level >= 0; level--) LAUNCH(k_lbvh_refit, h_lv[level].y, A, level);
+    info.n_nodes = h_lv[depth - 1].x + h_lv[depth - 1].y;
+  }
+  LAUNCH(k_lbvh_root, 1, A, root_ref, out);
+  float h_out[6];
+  HIP_TRY(hipMemcpyAsync(h_out, out, sizeof h_out, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  D.root_ref = root_ref;
+  for (int k = 0; k < 6; k++) D.bounds[k] = h_out[k];
+  return RT_OK;
+}
+
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -605,14 +727,16 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     inst.push_back(I);
   }
 
-  // ---- meshes
+  // ---- meshes: trees that came with the mesh are converted here and stand first in the node / slot arrays; meshes without
+  // one get their range behind them and are built on the device further down (lbvh_build)
   std::vector<DMesh> meshes(sc->n_meshes);
+  std::vector<MeshInfo> minfo(sc->n_meshes);
   int max_mesh_depth = 0;
   std::vector<float4> bvh, tris;
   std::vector<float4> shade;   // DScene::shade
   for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
     const rt_mesh& m = sc->meshes[mi];
-    if (!m.positions || !m.normals || !m.pos_idx || !m.nrm_idx || !m.bvh || m.n_bvh_nodes == 0 || (m.n_faces && !m.bvh_elements))
+    if (!m.positions || !m.normals || !m.pos_idx || !m.nrm_idx || (m.bvh && (m.n_bvh_nodes == 0 || (m.n_faces && !m.bvh_elements))))
       return fail(ctx, RT_ERR_INVALID, "mesh with missing arrays");
     for (size_t k = 0; k < 3 * (size_t)m.n_faces; k++) {
       if (m.pos_idx[k] >= m.n_positions || m.nrm_idx[k] >= m.n_normals) return fail(ctx, RT_ERR_INVALID, "mesh index out of range");
@@ -620,6 +744,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     }
     DMesh& D = meshes[mi];
     std::memset(&D, 0, sizeof D);
+    if (!m.bvh) continue;
     MeshConv cv(m, bvh, tris);
     uint32_t root;
     if (!cv.convert(0, 0, root)) return fail(ctx, RT_ERR_INVALID, "mesh BVH: " + cv.err);
@@ -629,6 +754,24 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     D.root_ref = root;
     const rt_bvh_node& r = m.bvh[0];
     for (int k = 0; k < 3; k++) { D.bounds[k] = r.bmin[k]; D.bounds[3 + k] = r.bmax[k]; }
+    minfo[mi].n_nodes = cv.n_internal; minfo[mi].n_slots = cv.n_slots;
+  }
+  size_t dev_nodes = 0, dev_slots = 0;   // float4s behind the converted part
+  for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
+    const rt_mesh& m = sc->meshes[mi];
+    if (m.bvh) continue;
+    if ((unsigned long long)m.n_faces > (1ull << 27)) return fail(ctx, RT_ERR_UNSUPPORTED, "mesh too large for the device BVH build");
+    DMesh& D = meshes[mi];
+    if ((bvh.size() + dev_nodes + 4 * (size_t)m.n_faces) >> 32 || (tris.size() + dev_slots + 3 * (size_t)m.n_faces) >> 32)
+      return fail(ctx, RT_ERR_UNSUPPORTED, "mesh arrays beyond 2^32 entries");
+    D.node_base = (uint32_t)(bvh.size() + dev_nodes);
+    D.tri_base = (uint32_t)(tris.size() + dev_slots);
+    dev_nodes += 4 * (size_t)std::max<uint32_t>(m.n_faces, 1u);
+    dev_slots += 3 * (size_t)std::max<uint32_t>(m.n_faces, 1u);
+  }
+  for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
+    const rt_mesh& m = sc->meshes[mi];
+    DMesh& D = meshes[mi];
     if ((shade.size() / 5 + (size_t)m.n_faces) >> 32) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^32 faces");
     D.shade_base = (uint32_t)(shade.size() / 5);
     const bool has_uvw = m.uvw && m.uvw_idx;
@@ -722,9 +865,24 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   int rc;
   if ((rc = upload(ctx, ctx->scene_mem, xf, &D.xf))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, inst, &D.inst))) return rc;
+  {  // node and slot arrays: the converted trees, then the trees built here
+    void *d_bvh, *d_tris;
+    if ((rc = alloc_dev(ctx, ctx->scene_mem, (bvh.size() + dev_nodes) * sizeof(float4), &d_bvh))) return rc;
+    if ((rc = alloc_dev(ctx, ctx->scene_mem, (tris.size() + dev_slots) * sizeof(float4), &d_tris))) return rc;
+    if (!bvh.empty()) HIP_TRY(hipMemcpy(d_bvh, bvh.data(), bvh.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!tris.empty()) HIP_TRY(hipMemcpy(d_tris, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    D.bvh = (const float4*)d_bvh;
+    D.tris = (const float4*)d_tris;
+    for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
+      if (sc->meshes[mi].bvh) continue;
+      int depth = 0;
+      if ((rc = lbvh_build(ctx, sc->meshes[mi], (float4*)d_bvh + meshes[mi].node_base, (float4*)d_tris + meshes[mi].tri_base, meshes[mi], minfo[mi], depth)))
+        return rc;
+      if (depth > RT_STACK) return fail(ctx, RT_ERR_INVALID, "mesh BVH: BVH deeper than 32 levels");
+      max_mesh_depth = std::max(max_mesh_depth, depth);
+    }
+  }
   if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, bvh, &D.bvh))) return rc;
-  if ((rc = upload(ctx, ctx->scene_mem, tris, &D.tris))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, shade, &D.shade))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, mtls, &D.materials))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, tms, &D.texmaps))) return rc;
@@ -787,7 +945,68 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   ctx->camera = sc->camera;
   ctx->n_nodes = (int)sc->n_nodes;
   ctx->h_inst = inst;
+  ctx->h_meshes = meshes;
+  ctx->h_minfo = minfo;
   ctx->has_scene = true;
+  return RT_OK;
+}
+
+int rt_scene_mesh_bvh(rt_context* ctx, int mesh_id, rt_bvh_node* nodes, uint32_t node_cap, uint32_t* elements, uint32_t elem_cap,
+                      uint32_t* n_nodes, uint32_t* n_elements) {
+  if (!ctx || !n_nodes || !n_elements) return RT_ERR_INVALID;
+  quiesce(ctx);
+  if (!ctx->has_scene) return fail(ctx, RT_ERR_NOSCENE, "no scene committed");
+  if (mesh_id < 0 || (size_t)mesh_id >= ctx->h_meshes.size()) return fail(ctx, RT_ERR_INVALID, "mesh index out of range");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const DMesh& D = ctx->h_meshes[mesh_id];
+  const MeshInfo& I = ctx->h_minfo[mesh_id];
+  std::vector<float4> hn(4 * (size_t)I.n_nodes), ht(3 * (size_t)I.n_slots);
+  if (!hn.empty()) HIP_TRY(hipMemcpy(hn.data(), ctx->ds.bvh + D.node_base, hn.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  if (!ht.empty()) HIP_TRY(hipMemcpy(ht.data(), ctx->ds.tris + D.tri_base, ht.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  auto f2u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  struct Item { uint32_t ref; float box[6]; int64_t parent; int right; };
+  std::vector<rt_bvh_node> out;
+  std::vector<uint32_t> el;
+  std::vector<Item> stack;
+  Item root;
+  root.ref = D.root_ref; root.parent = -1; root.right = 0;
+  for (int k = 0; k < 6; k++) root.box[k] = D.bounds[k];
+  stack.push_back(root);
+  while (!stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    const uint32_t me = (uint32_t)out.size();
+    rt_bvh_node n;
+    for (int k = 0; k < 3; k++) { n.bmin[k] = it.box[k]; n.bmax[k] = it.box[3 + k]; }
+    n.a = n.b = 0;
+    if (it.parent >= 0) (it.right ? out[it.parent].b : out[it.parent].a) = me;
+    if (it.ref & RT_LEAF) {
+      const uint32_t first = (it.ref & ~RT_LEAF) >> 3, count = it.ref & 7u;
+      if ((size_t)first + count > I.n_slots) return fail(ctx, RT_ERR_DEVICE, "mesh BVH: leaf outside the slot array");
+      n.a = (uint32_t)el.size();
+      n.b = RT_BVH_LEAF_BIT | count;
+      for (uint32_t s = 0; s < count; s++) el.push_back(f2u(ht[3 * (size_t)(first + s) + 1].w));
+      out.push_back(n);
+      continue;
+    }
+    if (it.ref >= I.n_nodes || out.size() > 2 * (size_t)I.n_slots + 2) return fail(ctx, RT_ERR_DEVICE, "mesh BVH: node outside the node array");
+    out.push_back(n);
+    const float4 x = hn[4 * (size_t)it.ref], y = hn[4 * (size_t)it.ref + 1], z = hn[4 * (size_t)it.ref + 2], r = hn[4 * (size_t)it.ref + 3];
+    Item l, rr;
+    l.ref = f2u(r.x); l.parent = me; l.right = 0;
+    l.box[0] = x.x; l.box[1] = y.x; l.box[2] = z.x; l.box[3] = x.z; l.box[4] = y.z; l.box[5] = z.z;
+    rr.ref = f2u(r.y); rr.parent = me; rr.right = 1;
+    rr.box[0] = x.y; rr.box[1] = y.y; rr.box[2] = z.y; rr.box[3] = x.w; rr.box[4] = y.w; rr.box[5] = z.w;
+    stack.push_back(rr);
+    stack.push_back(l);
+  }
+  *n_nodes = (uint32_t)out.size();
+  *n_elements = (uint32_t)el.size();
+  if (!nodes) return RT_OK;
+  if (node_cap < out.size() || elem_cap < el.size() || (!elements && !el.empty())) return fail(ctx, RT_ERR_INVALID, "capacity too small for the mesh BVH");
+  std::memcpy(nodes, out.data(), out.size() * sizeof(rt_bvh_node));
+  if (!el.empty()) std::memcpy(elements, el.data(), el.size() * sizeof(uint32_t));
   return RT_OK;
 }
 
@@ -893,18 +1112,6 @@ void collect_profile(rt_context* ctx, const std::vector<uint32_t>& counts) {
 
 // ---- photon pass (RayTracer::GeneratePhotons, RayTracer.cpp:262-294); kernels in rt_photon.h / rt_photon_build.h
 
-// One slab of device memory cut into 256-byte aligned pieces.
-struct Carver {
-  unsigned char* base = nullptr;
-  size_t used = 0;
-  template <class T>
-  T* take(size_t count) {
-    T* p = base ? (T*)(base + used) : nullptr;
-    used += (count * sizeof(T) + 255) & ~(size_t)255;
-    return p;
-  }
-};
-
 template <class Load>
 void scan_u2(rt_context* ctx, Load ld, uint32_t n, uint2* tiles, uint2* out) {
   if (n == 0) return;
@@ -916,21 +1123,6 @@ void scan_u2(rt_context* ctx, Load ld, uint32_t n, uint2* tiles, uint2* out) {
 #else
   k_scan_write(ld, n, tiles, out);
 #endif
-}
-
-// stable sort of (key, value) pairs on bits [0, end_bit) of the key
-int sort_pairs(rt_context* ctx, void* tmp, size_t tmp_bytes, const unsigned long long* kin, unsigned long long* kout, const uint32_t* vin,
-               uint32_t* vout, size_t n, int end_bit) {
-#ifndef RT_EMU
-  if (rt_sort_pairs_u64(tmp, &tmp_bytes, kin, kout, vin, vout, n, end_bit, (void*)ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "device sort failed");
-#else
-  std::vector<uint32_t> order(n);
-  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-  const unsigned long long mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (kin[a] & mask) < (kin[b] & mask); });
-  for (size_t i = 0; i < n; i++) { kout[i] = kin[order[i]]; vout[i] = vin[order[i]]; }
-#endif
-  return RT_OK;
 }
 
 int photon_ensure_buffers(PhotonState& ps, rt_context* ctx, int which, size_t n) {
@@ -2144,6 +2336,19 @@ int rt_counters_get(rt_context* ctx, rt_counters* out) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out, ctx->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost));
   out->paths += ctx->host_paths;
+#ifdef RT_SHADE_STATS
+  {
+    unsigned long long ss[16];
+    if (hipMemcpyFromSymbol(ss, HIP_SYMBOL(g_shade_stats), sizeof ss) == hipSuccess) {
+      static const char* nm[11] = {"claim/loop", "entry load", "finalize_hit", "miss/light/setup", "textures", "refraction", "reflection", "mc/emission", "aov+children", "light loop", "gather push"};
+      double tt = 0;
+      for (int i = 0; i < 11; i++) tt += (double)ss[i];
+      std::fprintf(stderr, "shade cycles:");
+      for (int i = 0; i < 11; i++) std::fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)ss[i] / (tt > 0 ? tt : 1));
+      std::fprintf(stderr, " (total %.3g wave-cycles)\n", tt);
+    }
+  }
+#endif
 #ifdef RT_WALK_STATS
   {
     unsigned long long ws[16];

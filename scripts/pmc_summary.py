@@ -12,10 +12,10 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.match(r"(?:void )?(k_\w+)(<(\w+)>)?", name)
+    m = re.match(r"(?:void )?(k_\w+)(<([\w, ]+)>)?", name)
     if not m:
         return None
-    return m.group(1) + (("<" + m.group(3) + ">") if m.group(3) else "")
+    return m.group(1) + (("<" + m.group(3).replace(" ", "") + ">") if m.group(3) else "")
 
 
 def fold(dirname):

@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests."""
+import ctypes as C
+
 import numpy as np
 
 from raytracer_amd import default_params, rays_from_arrays
@@ -380,14 +382,14 @@ def check_async_render(r, scene, w, h, spp):
     return seen
 
 
-def check_stress_scene(r, scene, w, h, n_rays):
+def check_stress_scene(r, scene, w, h, n_rays, oracle_scene=None):
     """BASELINE config 5's workload shape (rth_scene_generate_stress: icospheres over a displaced ground in ONE mesh,
     two sphere lights): node + face ids bit-exact at the pixel centre, batched closest / any-hit parity, and a
     stochastic frame with soft shadows and three bounces."""
     import oracle_ffi
     from raytracer_amd import RT_HIT_FRONT, RT_HIT_FRONT_AND_BACK
     r.LoadScene(scene)
-    orc = oracle_ffi.OracleScene(scene)
+    orc = oracle_ffi.OracleScene(oracle_scene if oracle_scene is not None else scene)
     p = params(w, h, spp=1, jitter=0, bounces=0)
     g, c = r.Render(p), orc.render(p)
     assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
@@ -404,6 +406,63 @@ def check_stress_scene(r, scene, w, h, n_rays):
     occ = orc.trace_any(rays, tmax)
     assert np.array_equal(r.TraceShadowRay(rays, tmax), occ) and 0.05 < occ.mean() < 0.95
     return g, c
+
+
+def mesh_arrays(m):
+    """positions (nv, 3) and position index triples (nf, 3) of an rt_mesh"""
+    pos = np.ctypeslib.as_array(m.positions, shape=(m.n_positions, 3)).copy()
+    idx = np.ctypeslib.as_array(m.pos_idx, shape=(m.n_faces, 3)).copy()
+    return pos, idx
+
+
+def assert_bvh_valid(nodes, elems, m, max_depth=32):
+    """A tree in rt_mesh form is a BVH of mesh m: every face in exactly one leaf, leaves of 1..4 faces, every child box
+    inside its parent's, every triangle inside its leaf's box, no leaf deeper than the walk's stack."""
+    from raytracer_amd import _ffi
+    leaf = np.uint32(_ffi.RT_BVH_LEAF_BIT) if hasattr(_ffi, "RT_BVH_LEAF_BIT") else np.uint32(0x80000000)
+    pos, idx = mesh_arrays(m)
+    tri_lo, tri_hi = pos[idx].min(axis=1), pos[idx].max(axis=1)
+    is_leaf = (nodes["b"] & leaf) != 0
+    cnt = (nodes["b"][is_leaf] & ~leaf).astype(np.int64)
+    assert m.n_faces <= 4 or ((cnt >= 1) & (cnt <= 4)).all()
+    assert cnt.sum() == len(elems) == m.n_faces and np.array_equal(np.sort(elems), np.arange(m.n_faces, dtype=np.uint32))
+    inner = np.nonzero(~is_leaf)[0]
+    for side in ("a", "b"):
+        ch = nodes[side][inner]
+        assert (ch > inner).all() and (ch < len(nodes)).all()          # pre-order: children behind their parent
+        assert (nodes["bmin"][ch] >= nodes["bmin"][inner]).all() and (nodes["bmax"][ch] <= nodes["bmax"][inner]).all()
+    assert len(np.unique(np.concatenate([nodes["a"][inner], nodes["b"][inner]]))) == len(nodes) - 1   # a tree: every node but the root has one parent
+    lf = np.nonzero(is_leaf)[0]
+    owner = np.repeat(lf, cnt)
+    first = nodes["a"][lf].astype(np.int64)
+    assert np.array_equal(first, np.concatenate([[0], np.cumsum(cnt)[:-1]]))   # leaves own consecutive runs of the element list
+    assert (tri_lo[elems] >= nodes["bmin"][owner]).all() and (tri_hi[elems] <= nodes["bmax"][owner]).all()
+    depth = np.zeros(len(nodes), np.int32)
+    for i in inner:            # pre-order: a parent is numbered before its children
+        depth[nodes["a"][i]] = depth[nodes["b"][i]] = depth[i] + 1
+    assert depth.max() <= max_depth
+    return int(depth.max())
+
+
+def check_device_bvh(r, scene, w, h, n_rays):
+    """n2: TriObj::Load's BVH (objects.h:60-67).  (1) A tree that comes with the mesh survives rt_scene_commit: what
+    rt_scene_mesh_bvh hands back is the tree that went in.  (2) A mesh WITHOUT a tree gets one built on the device: it is a
+    valid BVH of the mesh, and with the oracle walking that same tree the hit ids are bit-exact and the batched queries agree
+    (check_stress_scene)."""
+    r.LoadScene(scene)
+    nm = scene.desc.n_meshes
+    for i in range(nm):
+        m = scene.desc.meshes[i]
+        nodes, elems = r.GetMeshBVH(i)
+        ref = np.ctypeslib.as_array(C.cast(m.bvh, C.POINTER(C.c_uint32)), shape=(m.n_bvh_nodes * 8,))
+        assert np.array_equal(nodes.view(np.uint32), ref), "host-built tree changed on the way through the commit"
+        assert np.array_equal(elems, np.ctypeslib.as_array(m.bvh_elements, shape=(m.n_bvh_elements,)))
+    bare = scene.with_bvh({i: None for i in range(nm)})
+    r.LoadScene(bare)
+    trees = {i: r.GetMeshBVH(i) for i in range(nm)}
+    depths = [assert_bvh_valid(trees[i][0], trees[i][1], scene.desc.meshes[i]) for i in range(nm)]
+    g, c = check_stress_scene(r, bare, w, h, n_rays, oracle_scene=scene.with_bvh(trees))
+    return trees, depths
 
 
 def check_reference_scene_fixtures(r, w, h, strict=None):

@@ -86,6 +86,41 @@ def test_stress_scene_scaled(emu):
     assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
 
 
+def test_device_bvh_build(emu, tmp_path):
+    """Meshes without a tree get a linear BVH at rt_scene_commit (here: the same kernels under host emulation); a tree that
+    comes with the mesh is handed back unchanged by rt_scene_mesh_bvh."""
+    scene = Scene.stress(seed=3, n_instances=12, subdiv=2, ground_res=40, width=96, height=54)
+    trees, depths = common_checks.check_device_bvh(emu, scene, 96, 54, n_rays=800)
+    assert 8 <= depths[0] <= 28
+    # Scene.stress(host_bvh=False) hands the mesh over without a tree in the first place
+    bare = Scene.stress(seed=3, n_instances=12, subdiv=2, ground_res=40, width=96, height=54, host_bvh=False)
+    assert not bare.desc.meshes[0].bvh and bare.desc.meshes[0].n_bvh_nodes == 0
+    emu.LoadScene(bare)
+    again = emu.GetMeshBVH(0)
+    assert np.array_equal(again[0].view(np.uint32), trees[0][0].view(np.uint32)) and np.array_equal(again[1], trees[0][1])
+    # tiny meshes: one leaf, and a mesh of exactly 5 faces (one split); many faces with the same centre (equal codes)
+    for n_faces, same in ((1, False), (4, False), (5, False), (40, True)):
+        with open(tmp_path / f"tiny{n_faces}.obj", "w") as f:
+            for k in range(n_faces):
+                x = 0.0 if same else 1.5 * k
+                s_ = 1.0 + (0.01 * k if same else 0.0)
+                f.write(f"v {x - s_} {-s_} 0\nv {x + s_} {-s_} {0.1 * k}\nv {x + s_} {s_} 0\nv {x - s_} {s_} {0.1 * k}\n")
+            for k in range(n_faces):
+                f.write(f"f {4 * k + 1} {4 * k + 2} {4 * k + 4}\n" if not same else f"f {4 * k + 1} {4 * k + 3} {4 * k + 2}\n")
+        tiny = Scene.from_string(f"""<xml><scene><object type="obj" name="tiny{n_faces}.obj" material="m"/>
+<material type="blinn" name="m"><diffuse value="0.5"/></material><light type="direct"><intensity value="1"/><direction x="0" y="0" z="-1"/></light>
+</scene><camera><position x="0" y="-1" z="30"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="40"/>
+<width value="32"/><height value="32"/></camera></xml>""", asset_dir=str(tmp_path), host_bvh=False)
+        assert tiny.desc.meshes[0].n_faces == n_faces
+        emu.LoadScene(tiny)
+        nodes, elems = emu.GetMeshBVH(0)
+        common_checks.assert_bvh_valid(nodes, elems, tiny.desc.meshes[0])
+        assert len(nodes) == (1 if n_faces <= 4 else 3) or same
+        p = params(32, 32, spp=1, jitter=0, bounces=0)
+        g, c = emu.Render(p), oracle_ffi.OracleScene(tiny.with_bvh({0: (nodes, elems)})).render(p)
+        assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face) and (g.hit_face >= 0).any()
+
+
 def test_steady_state_calls_do_not_allocate(emu):
     """Entry points keep their device buffers in the context (grow-only): repeating a call allocates nothing."""
     scene = Scene.load(scene_path("cornell_box.xml"))

@@ -59,6 +59,26 @@ def test_c5_stress_scene_scaled(gpu_renderer):
     print("c5 scaled:", cc.assert_stochastic_close(g, c, "stress scene"))
 
 
+def test_device_bvh_build(gpu_renderer):
+    """n2: meshes without a tree get a linear BVH on the device at rt_scene_commit (rt_bvh_build.h): a valid BVH of the mesh,
+    and with the oracle walking the SAME tree (rt_scene_mesh_bvh) node + face ids are bit-exact and the batched closest /
+    any-hit queries agree — on the scaled stress scene (227k triangles in one mesh) and on C2's instanced meshes."""
+    import oracle_ffi
+    scene = Scene.stress(seed=7, n_instances=96, subdiv=3, ground_res=230, width=480, height=270)
+    trees, depths = cc.check_device_bvh(gpu_renderer, scene, 480, 270, n_rays=20000)
+    print("device BVH of the scaled stress scene: depth", depths, "nodes", [len(t[0]) for t in trees.values()])
+    c2 = Scene.load(scene_path("c2_mesh_room.xml"))
+    bare = c2.with_bvh({i: None for i in range(c2.desc.n_meshes)})
+    gpu_renderer.LoadScene(bare)
+    built = {i: gpu_renderer.GetMeshBVH(i) for i in range(c2.desc.n_meshes)}
+    for i in built:
+        cc.assert_bvh_valid(built[i][0], built[i][1], c2.desc.meshes[i])
+    p = params(480, 270, spp=1, jitter=0, bounces=3)
+    g, c = gpu_renderer.Render(p), oracle_ffi.OracleScene(c2.with_bvh(built)).render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
+    assert cc.rel_colour_diff(g.radiance, c.radiance) <= 1e-4
+
+
 def test_c5_stress_scene_full_size(gpu_renderer):
     """BASELINE config 5 at full size (12.6 M triangles in one BVH, 4K): properties that need no full CPU render — no
     queue overflow / walk abort (the call succeeds), every pixel sampled, the frame's two-phase kernels and the batched
