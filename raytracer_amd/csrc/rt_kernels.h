@@ -97,7 +97,8 @@ struct PassP {
 
 struct FrameBufs {
   const uint32_t* pixels;  // pixel indices of this pass, ordered in 8x8 tiles
-  float4* path_rad;        // n_pix * n_samples path radiance slots
+  float* path_rad;         // n_pix * n_samples path radiance slots, one plane per colour channel (rad_stride floats apart): the
+  uint32_t rad_stride;     // kernels add with one float atomic per channel, and 64 lanes' slots then share 4 cache lines, not 16
   float* accum;            // W*H*8: sum rgb, n, sum of squares rgb, done flag
   int32_t* hit_node;       // W*H AOVs (may be null)
   int32_t* hit_face;
@@ -300,7 +301,7 @@ RT_KERNEL(k_raygen_trace, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ) {
       uint4 m;
       m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
       Q.q3[qi] = m;
-      F.path_rad[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      F.path_rad[idx] = 0.0f; F.path_rad[(size_t)F.rad_stride + idx] = 0.0f; F.path_rad[2 * (size_t)F.rad_stride + idx] = 0.0f;
       traced++;
     }
     // primary rays see front faces only (RayTracer.cpp:233)
@@ -619,10 +620,13 @@ RT_DEV void shade_draws(const PassP& P, const ShadePt& sp, uint32_t block, float
 }
 
 RT_DEV void add_radiance(const FrameBufs& F, uint32_t slot, V3 c) {
-  float* p = (float*)&F.path_rad[slot];
-  if (c.x != 0.0f) rt_atomic_add_f32(p + 0, c.x);
-  if (c.y != 0.0f) rt_atomic_add_f32(p + 1, c.y);
-  if (c.z != 0.0f) rt_atomic_add_f32(p + 2, c.z);
+#ifdef RT_EXP_NO_RADIANCE   // timing experiment only: what the radiance atomics cost
+  if (slot != 0xFFFFFFF0u) return;
+#endif
+  float* p = F.path_rad + slot;
+  if (c.x != 0.0f) rt_atomic_add_f32(p, c.x);
+  if (c.y != 0.0f) rt_atomic_add_f32(p + F.rad_stride, c.y);
+  if (c.z != 0.0f) rt_atomic_add_f32(p + 2 * (size_t)F.rad_stride, c.z);
 }
 
 RT_DEV V3 absorb(V3 c, V3 ab, float dist) {  // materials.cpp:255-259
@@ -1196,9 +1200,10 @@ RT_KERNEL(k_accumulate, PassP P, FrameBufs F) {
     float* a = F.accum + 8 * (size_t)pixel;
     float sr = a[0], sg = a[1], sb = a[2], n = a[3], qr = a[4], qg = a[5], qb = a[6], done = a[7];
     for (int k = 0; k < P.n_samples && done == 0.0f; k++) {
-      float4 c = F.path_rad[(size_t)k * P.n_pix + j];
-      sr += c.x; sg += c.y; sb += c.z;
-      qr += c.x * c.x; qg += c.y * c.y; qb += c.z * c.z;
+      const size_t slot = (size_t)k * P.n_pix + j;
+      const float cx = F.path_rad[slot], cy = F.path_rad[F.rad_stride + slot], cz = F.path_rad[2 * (size_t)F.rad_stride + slot];
+      sr += cx; sg += cy; sb += cz;
+      qr += cx * cx; qg += cy * cy; qb += cz * cz;
       n += 1.0f;
       if (P.adaptive) {
         int i = P.sample_base + k;

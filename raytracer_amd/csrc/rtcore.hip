@@ -154,7 +154,8 @@ struct rt_context {
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
   uint32_t* d_summary = nullptr; // k_pass_summary's output (allocated with the context)
   uint32_t* h_summary = nullptr; // ... and its pinned host copy
-  float4* d_path_rad = nullptr;
+  float* d_path_rad = nullptr;      // three planes of rad_stride floats
+  uint32_t rad_stride = 0;
   uint32_t* d_pixels = nullptr;
   uint32_t* d_pixels2 = nullptr;
   int32_t* d_hit_node = nullptr;
@@ -1585,8 +1586,9 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_meshq(ctx->MQ, fp.f[4], fp.f[7]))) return rc;
   if ((rc = alloc_meshq(ctx->MH, fp.n_hard ? fp.f[5] : 0.0, fp.f[8]))) return rc;
   if ((rc = alloc_meshq(ctx->MS, fp.n_soft ? fp.f[6] : 0.0, fp.f[9]))) return rc;
-  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 16, &p))) return rc;
-  ctx->d_path_rad = (float4*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 12, &p))) return rc;
+  ctx->d_path_rad = (float*)p;
+  ctx->rad_stride = (uint32_t)fp.budget;
   size_t npx = (size_t)fp.W * fp.H;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 4, &p))) return rc; ctx->d_pixels = (uint32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, npx * 8, &p))) return rc; ctx->d_pixels2 = (uint32_t*)p;
@@ -1884,6 +1886,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
 
   FrameBufs F;
   F.path_rad = ctx->d_path_rad;
+  F.rad_stride = ctx->rad_stride;
   F.accum = d_accum;
   F.hit_node = ctx->d_hit_node;
   F.hit_face = ctx->d_hit_face;
@@ -1990,6 +1993,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
     HIP_TRY(hipMemsetAsync(ctx->d_aov_normal, 0, (size_t)W * H * 12, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_aov_albedo, 0, (size_t)W * H * 12, ctx->stream));
     F.path_rad = ctx->d_path_rad;
+    F.rad_stride = ctx->rad_stride;
     F.hit_node = ctx->d_hit_node;
     F.hit_face = ctx->d_hit_face;
     F.aov_depth = ctx->d_aov_depth;
