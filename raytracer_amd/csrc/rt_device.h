@@ -327,6 +327,7 @@ RT_DEV float wave_max(float v) { return v; }
 RT_DEV uint32_t rt_lane() { return threadIdx.x & 63u; }
 RT_DEV uint32_t rt_wave_id() { return RT_TID >> 6; }
 RT_DEV uint32_t rt_num_waves() { return RT_NTHREADS >> 6; }
+RT_DEV uint32_t rt_wave_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }   // lane 0's value (all lanes active)
 RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
   unsigned long long mask = __ballot(pred);
   if (mask == 0) return RT_NONE;
@@ -349,6 +350,7 @@ RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t seg
 RT_DEV uint32_t rt_lane() { return 0u; }
 RT_DEV uint32_t rt_wave_id() { return 0u; }
 RT_DEV uint32_t rt_num_waves() { return 1u; }
+RT_DEV uint32_t rt_wave_first(uint32_t v) { return v; }
 RT_DEV uint32_t seg_push(bool pred, uint32_t* counts, uint32_t seg, uint32_t segcap, uint32_t* overflow) {
   if (!pred) return RT_NONE;
   uint32_t pos = counts[seg * RT_CSTRIDE]++;

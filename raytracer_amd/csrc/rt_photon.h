@@ -616,6 +616,7 @@ struct GatherP {
   uint32_t* retry;          // STAGE 1 -> 2: queue entries still to do, segmented like the queue itself
   float* retry_seed;        // ... and, for a lookup whose hinted bracket missed, where to start from (0: nothing known)
   uint32_t* retry_counts;
+  uint32_t* cursor;         // per segment (RT_CSTRIDE apart): entries of the stage's queue already claimed by some wave
 };
 
 // the shade kernel's deferred lookups (materials.cpp:315-322): indirect += (1/pi) * kd * E, weighted by the path weight
@@ -644,12 +645,27 @@ RT_DEV size_t gather_hint_slot(const GatherP& G, const FrameBufs& F, uint32_t sl
 // STAGE 0: every lookup from scratch (no hint buffer).  With hints the queue is taken in two stages, because a wave is
 // as slow as its slowest lane: STAGE 1 tries every hinted lookup (one walk + the exception test) and lists the ones
 // without a hint or whose bracket missed; STAGE 2 runs the listed lookups from scratch, packed densely into waves.
+// Lookups differ a lot in length, so the waves CLAIM the queue 64 entries at a time (one atomic per wave and claim, on the
+// segment's cursor) instead of being dealt fixed shares: a wave that drew short lookups takes more of them, and the launch
+// ends when the queue is empty, not when the unluckiest wave has finished its share.
 template <bool CNT, int STAGE>
 RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q) {
   RT_HEAP_DECL(G.depth)
   uint32_t visits = 0, gathers = 0;
   float guess[2] = {0.0f, 0.0f};  // per map: the squared radius the lane's previous lookup needed
-  RT_SEG_BEGIN((STAGE == 2 ? G.retry_counts : Q.counts), Q.nseg, Q.segcap, 1u)
+  const uint32_t* seg_counts = STAGE == 2 ? G.retry_counts : Q.counts;
+  struct { uint32_t s; } sw_;
+  sw_.s = rt_wave_id() % Q.nseg;
+  for (uint32_t segs_done = 0; segs_done < Q.nseg;) {
+    uint32_t seg_n_ = seg_counts[sw_.s * RT_CSTRIDE];
+    if (seg_n_ > Q.segcap) seg_n_ = Q.segcap;
+    uint32_t e0_ = 0;
+    if (rt_lane() == 0) e0_ = rt_atomic_add_u32(G.cursor + sw_.s * RT_CSTRIDE, RT_WAVE);
+    e0_ = rt_wave_first(e0_);
+    if (e0_ >= seg_n_) { sw_.s = (sw_.s + 1) % Q.nseg; segs_done++; continue; }
+    const uint32_t seg_base_ = sw_.s * Q.segcap;
+    const uint32_t seg_e = e0_ + rt_lane();
+    const bool seg_valid = seg_e < seg_n_;
     uint32_t g = seg_base_ + (uint32_t)seg_e;
     if (STAGE == 2 && seg_valid) g = G.retry[g];
     bool todo = seg_valid;   // (every lane reaches the append below)
@@ -709,7 +725,7 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
       uint32_t ri = seg_push(todo, G.retry_counts, sw_.s, Q.segcap, F.overflow);
       if (ri != RT_NONE) { G.retry[ri] = g; G.retry_seed[ri] = seed; }
     }
-  RT_SEG_END
+  }
   if (CNT) {
     if (visits) rt_atomic_add_u64(&F.counters->photon_visits, visits);
     if (gathers) rt_atomic_add_u64(&F.counters->gathers, gathers);

@@ -149,6 +149,7 @@ struct rt_context {
   GatherQ GQ;
   MeshQ MQ, MH, MS;
   uint32_t* d_list2 = nullptr;
+  uint32_t* d_gather_cursor = nullptr;  // GatherP::cursor, one slab per stage
   uint32_t* d_gather_retry = nullptr;   // GatherP::retry, retry_seed
   float* d_gather_seed = nullptr;
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
@@ -1405,8 +1406,11 @@ int photon_set(PhotonState& ps, rt_context* ctx, int which, const rt_photon* pho
   do {                                                                                                     \
     unsigned long long nb_ = ((unsigned long long)(n_items) + RT_GATHER_BLOCK - 1) / RT_GATHER_BLOCK;      \
     if (nb_ < 1) nb_ = 1;                                                                                  \
-    if (nb_ > (unsigned long long)ctx->max_blocks_trace * 4) nb_ = (unsigned long long)ctx->max_blocks_trace * 4;\
     size_t lds_ = photon_heap_bytes(depth_);                                                                 \
+    /* one-wave blocks, as many as are resident at once (RT_GATHER_WAVES per SIMD, LDS permitting): the queue is dealt to \
+       the waves statically, so a grid larger than that runs as a full round plus a thin one */               \
+    unsigned long long res_ = (unsigned long long)ctx->n_cus * std::min<unsigned long long>(4ull * RT_GATHER_WAVES, (160u * 1024u) / std::max<size_t>(lds_, 1)); \
+    if (nb_ > res_) nb_ = res_;                                                                            \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);   \
     hipLaunchKernelGGL(kern, dim3((unsigned)nb_), dim3(RT_GATHER_BLOCK), lds_, ctx->stream, __VA_ARGS__);  \
   } while (0)
@@ -1471,20 +1475,28 @@ void photon_gather_queue(rt_context* ctx, const GatherQ& GQ, const FrameBufs& F,
   G.retry_seed = ctx->d_gather_seed;
   G.retry_counts = retry_counts;
   G.pilot = 0;
+  // one stage-1 / stage-2 launch pair (or the single stage-0 launch); the waves claim the queues through cursors that start at 0
+  auto stage = [&](int st) {
+    G.cursor = ctx->d_gather_cursor + (st == 2 ? CNT_SLAB : 0);
+    (void)hipMemsetAsync(G.cursor, 0, CNT_SLAB * sizeof(uint32_t), ctx->stream);
+    if (st == 0) LAUNCH_GATHER((k_photon_gather<CNT, 0>), upper, G.depth, G, F, GQ);
+    else if (st == 1) LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
+    else LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+  };
   if (G.hints && ctx->gather_hints_cold) {
     // no hints yet (first pass after a commit): pilot lookups from scratch, then the rest from the hints they leave
     G.pilot = 1;
-    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
-    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+    stage(1);
+    stage(2);
     (void)hipMemsetAsync(retry_counts, 0, CNT_SLAB * sizeof(uint32_t), ctx->stream);
     G.pilot = 2;
-    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
-    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+    stage(1);
+    stage(2);
   } else if (G.hints) {
-    LAUNCH_GATHER((k_photon_gather<CNT, 1>), upper, G.depth, G, F, GQ);
-    LAUNCH_GATHER((k_photon_gather<CNT, 2>), upper, G.depth, G, F, GQ);
+    stage(1);
+    stage(2);
   } else {
-    LAUNCH_GATHER((k_photon_gather<CNT, 0>), upper, G.depth, G, F, GQ);
+    stage(0);
   }
 }
 
@@ -1566,6 +1578,7 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.b = (float4*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 16, &p))) return rc; ctx->GQ.c = (float4*)p;
   ctx->GQ.counts = nullptr;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, 2 * CNT_SLAB * sizeof(uint32_t), &p))) return rc; ctx->d_gather_cursor = (uint32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_retry = (uint32_t*)p;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, gsegcap * NSEG * 4, &p))) return rc; ctx->d_gather_seed = (float*)p;
   auto alloc_meshq = [&](MeshQ& q, double f, double fc) {
