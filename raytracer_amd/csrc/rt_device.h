@@ -90,6 +90,14 @@ struct DMaterial {
   float absorption[3];
   float ior;
 };
+struct DShadeInst {     // what k_shade needs of a hit instance in ONE record: the instance header's shading fields and a copy
+  int32_t prim, node;   // of its material, so that the material is not a second dependent fetch behind the instance
+  int32_t depth, xf_off;
+  uint32_t shade_base, has_uvw;
+  uint32_t pad_[2];
+  DMaterial mtl;
+  uint32_t pad2_;
+};
 struct DLight {
   int32_t kind;
   float intensity[3], position[3], direction[3];
@@ -98,6 +106,7 @@ struct DLight {
 
 struct DScene {
   const DInstance* inst;
+  const DShadeInst* sinst;  // same index as inst
   const float* xf;      // transform chains, see DInstance::xf_off
   const DMesh* meshes;
   const float4* bvh;
@@ -934,7 +943,8 @@ RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, uint3
 
 // Hit attributes of the winner (objects.cpp:37-43, 135-138, 303-320), Node::FromNodeCoords back up the chain
 // (scene.h:184-189), then the renderable lights (RayTracer.cpp:413-432).
-RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit) {
+template <class InstT>   // DInstance, or k_shade's DShadeInst (same field names)
+RT_DEV bool finalize_hit_from(const DScene& S, const InstT* table, V3 o, V3 dir, const Best& B, Hit& hit) {
   const float best_t = B.t;
   const int best_inst = B.inst;
   hit.inst = -1; hit.face = -1; hit.light = -1; hit.front = true; hit.z = RT_BIG;
@@ -942,7 +952,7 @@ RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit)
   bool any = false;
   if (best_inst >= 0) {
     any = true;
-    const DInstance& I = S.inst[best_inst];  // per-lane index: ordinary loads
+    const InstT& I = table[best_inst];  // per-lane index: ordinary loads
     const float* chain = S.xf + I.xf_off;
     V3 p = o, d = dir;
     for (int k = 0; k < I.depth; k++) {
@@ -1002,6 +1012,8 @@ RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit)
   }
   return any;
 }
+
+RT_DEV bool finalize_hit(const DScene& S, V3 o, V3 dir, const Best& B, Hit& hit) { return finalize_hit_from(S, S.inst, o, dir, B, hit); }
 
 template <bool CNT>
 RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {

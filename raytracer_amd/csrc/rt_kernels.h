@@ -264,13 +264,13 @@ RT_DEV void write_raw(const RayQ& Q, uint32_t idx, const Best& B) {
   Q.r0[idx] = make_float4(B.t, B.mh.u, B.mh.v, __uint_as_float((uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u)));
   Q.rf[idx] = B.mh.face;
 }
-RT_DEV void read_raw(const RayQ& Q, uint32_t idx, Best& B) {
-  float4 r = Q.r0[idx];
+RT_DEV void unpack_raw(float4 r, uint32_t face, Best& B) {
   uint32_t w = __float_as_uint(r.w);
   B.t = r.x; B.mh.u = r.y; B.mh.v = r.z; B.mh.t = r.x; B.mh.key = 0;
   B.inst = (int)(w & 0x7fffffffu) - 1; B.front = (w >> 31) != 0;
-  B.mh.face = Q.rf[idx];
+  B.mh.face = face;
 }
+RT_DEV void read_raw(const RayQ& Q, uint32_t idx, Best& B) { unpack_raw(Q.r0[idx], Q.rf[idx], B); }
 
 // Camera rays and their first phase in one kernel: the ray is generated, written to the level-0 queue (k_shade and
 // k_trace_mesh read it) and taken through the instance table while still in registers (separate kernels re-read 48 bytes
@@ -678,9 +678,17 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
     const uint32_t oseg = sw_.s % QN.nseg;  // children and shadow work stay in the parent's segment
     uint32_t idx = seg_base_ + (uint32_t)seg_e;
     bool valid = seg_valid;
+    // the whole entry is requested at once (ids, ray, weights, raw hit): one memory round trip per iteration instead of
+    // ids first, then whatever they select
     uint4 m;
     m.x = m.y = m.z = 0; m.w = 0;
-    if (valid) m = Q.q3[idx];
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, raw0 = q0;
+    uint32_t raw_face = 0;
+    if (valid) {
+      m = Q.q3[idx];
+      q0 = Q.q0[idx]; q1 = Q.q1[idx]; q2 = Q.q2[idx];
+      raw0 = Q.r0[idx]; raw_face = Q.rf[idx];   // (stale for a re-shade entry, which brings its own hit record)
+    }
     uint32_t slot = m.x, pixel = m.y;
     uint32_t nid = m.w & 0xFFFu, bounce = (m.w >> 12) & 7u;
     bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
@@ -702,7 +710,6 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
     V3 wk = v3(0, 0, 0);
 
     if (valid) {
-      float4 q0 = Q.q0[idx], q1 = Q.q1[idx], q2 = Q.q2[idx];
       float4 h0;
       if (reshade) {  // the hit record k_shade wrote for this entry (lights.cpp:172-183)
         h0 = Q.h0[idx];
@@ -711,14 +718,14 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
       } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
         SPHASE(2);
         Best B;
-        read_raw(Q, idx, B);
+        unpack_raw(raw0, raw_face, B);
         Hit h;
-        finalize_hit(S, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
+        finalize_hit_from(S, S.sinst, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
         h0 = make_float4(h.p.x, h.p.y, h.p.z, h.z);
         h1 = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
         h2 = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float((h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8)));
         if (bounce == 0 && F.hit_node && (int)m.z == P.aov_sample) {
-          F.hit_node[pixel] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.inst[h.inst].node : -1);
+          F.hit_node[pixel] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.sinst[h.inst].node : -1);
           F.hit_face[pixel] = h.light >= 0 ? -1 : h.face;
         }
       }
@@ -766,7 +773,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         }
         n_shades++;
         aov_z = zs; aov_n = sp.N;
-        const DMaterial& M = S.materials[S.inst[inst].mtl];
+        const DMaterial& M = S.sinst[inst].mtl;
         if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
           add_radiance(F, slot, w);
         } else {

@@ -867,6 +867,17 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   int rc;
   if ((rc = upload(ctx, ctx->scene_mem, xf, &D.xf))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, inst, &D.inst))) return rc;
+  {
+    std::vector<DShadeInst> sinst(inst.size());
+    for (size_t i = 0; i < inst.size(); i++) {
+      DShadeInst& R = sinst[i];
+      std::memset(&R, 0, sizeof R);
+      R.prim = inst[i].prim; R.node = inst[i].node; R.depth = inst[i].depth; R.xf_off = inst[i].xf_off;
+      R.shade_base = inst[i].shade_base; R.has_uvw = inst[i].has_uvw;
+      R.mtl = mtls[inst[i].mtl];
+    }
+    if ((rc = upload(ctx, ctx->scene_mem, sinst, &D.sinst))) return rc;
+  }
   {  // node and slot arrays: the converted trees, then the trees built here
     void *d_bvh, *d_tris;
     if ((rc = alloc_dev(ctx, ctx->scene_mem, (bvh.size() + dev_nodes) * sizeof(float4), &d_bvh))) return rc;
