@@ -441,6 +441,10 @@ def main():
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": d["hbm_traffic_bytes_per_launch"],
+                         # what THIS build's counters say about the same roof (null without a matching PMC summary): HBM traffic
+                         # against 8 TB/s, or the share of VALU issue slots in use (at active_lane_ratio lanes per instruction)
+                         "measured_util": d["hbm_traffic_frac"] if bound == "hbm" else d["valu_issue_util"],
+                         "active_lane_ratio": d["active_lane_ratio"],
                          "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
                          "kernel_source_sha": src_sha, "pmc_summary": (pmc or {}).get("_meta", {}).get("file"),
                          "per_kernel": per_kernel,
