@@ -755,6 +755,7 @@ struct PhotonState {
   size_t raw_cap[2] = {0, 0}, tree_cap[2] = {0, 0};   // photons the device buffers hold
   int32_t count[2] = {0, 0};
   uint32_t emitted = 0;
+  uint32_t paths_needed[2] = {0, 0};   // paths it took to fill each map in the last build (0: unknown): sizes the next build's batches
 };
 
 static inline void photon_state_free(PhotonState& s) {
@@ -765,5 +766,7 @@ static inline void photon_state_free(PhotonState& s) {
     s.raw_cap[i] = s.tree_cap[i] = 0;
     s.count[i] = 0;
   }
+  s.emitted = 0;
+  s.paths_needed[0] = s.paths_needed[1] = 0;
   s.built = false;
 }

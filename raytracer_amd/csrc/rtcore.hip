@@ -1269,14 +1269,21 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
     if ((rc = photon_ensure_buffers(ps, ctx, w, n))) return rc;
   uint32_t kept[2] = {0, 0};
   uint32_t emitted = 0;
+  double needed[2] = {0.0, 0.0};   // paths after which each map was full (estimated within the batch that filled it)
   const bool timing = ctx->opt.timing != 0;   // developer aid: host-side phases of the build on stderr
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_start = now();
   int n_batches = 0;
   if (!plights.empty()) {
     uint32_t batch = 1u << 16, cap_batch = 1u << 21;
-    const uint32_t per_path = 16;  // deposit records a batch may add per path before the batch is retried smaller
-    const uint32_t cap = batch * per_path;
+    const uint32_t cap = batch * 16;   // deposit records a batch may add (16 per path of the smallest batch) before it is retried smaller
+    // A batch takes as long as its longest path (up to photon_max_bounces closest-hit queries in a row), however few
+    // paths it has: the build before this one says how many paths fill the maps, so that one batch does it.  Paths past
+    // the point where both maps are full deposit nothing that is kept (first n in emission order), so aiming high is safe.
+    // (first up to where the first map was full: past it that map's deposits would only fill the record buffers)
+    uint32_t plan[2] = {std::min(ps.paths_needed[0], ps.paths_needed[1]), std::max(ps.paths_needed[0], ps.paths_needed[1])};
+    auto planned = [&](uint32_t upto) { return std::min<uint32_t>(cap_batch, (upto + upto / 32 + 4095u) & ~4095u); };
+    if (plan[0] > batch) batch = planned(plan[0]);
     if (max_b > 255) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_max_bounces must be <= 255");
     Carver cv;
     float4* d_rec[2] = {nullptr, nullptr};
@@ -1346,11 +1353,21 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
         continue;
       }
       for (int w = 0; w < 2; w++)
-        if (PP.accept[w]) kept[w] = (uint32_t)std::min<unsigned long long>(n, (unsigned long long)kept[w] + h_cnt[w]);
+        if (PP.accept[w]) {
+          // the share of this batch's paths it took to fill map w (deposits are spread evenly over a batch's paths)
+          const double share = h_cnt[w] ? std::min(1.0, (double)(n - kept[w]) / (double)h_cnt[w]) : 1.0;
+          needed[w] = (double)emitted + share * (double)count;
+          kept[w] = (uint32_t)std::min<unsigned long long>(n, (unsigned long long)kept[w] + h_cnt[w]);
+        }
       emitted += count;
       // deposits into a map that still accepts them decide how many paths the record buffers can take per batch
       uint32_t densest = std::max(PP.accept[0] ? h_cnt[0] : 0u, PP.accept[1] ? h_cnt[1] : 0u);
-      while (batch < cap_batch && (uint64_t)densest * 8 < cap) { batch *= 2; densest *= 2; }
+      if (plan[1] > emitted + batch && (kept[0] >= n) != (kept[1] >= n)) {
+        batch = planned(plan[1] - emitted);   // one map is full: the rest of what the other needed last time, in one batch
+        plan[1] = 0;
+      } else {
+        while (batch < cap_batch && (uint64_t)densest * 8 < cap) { batch *= 2; densest *= 2; }
+      }
     }
   }
   const double t_emit = now();
@@ -1368,6 +1385,7 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
     collect_profile(ctx, none);
   }
   ps.emitted = emitted;
+  for (int w = 0; w < 2; w++) ps.paths_needed[w] = kept[w] >= n ? (uint32_t)std::min(needed[w], 4.0e9) : 0u;
   std::memcpy(ps.key, key, sizeof key);
   ps.built = true;
   return RT_OK;
