@@ -2,6 +2,8 @@
 single-threaded) against the recursive CPU oracle.  Exercises the queue-per-stage unrolling of the reference's
 recursion, the shadow-group phases, adaptive sampling, partitioning and the batched trace API where no GPU exists;
 the same comparisons run against the real HIP library in test_gpu_*.py."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -98,6 +100,19 @@ def test_device_bvh_build(emu, tmp_path):
     emu.LoadScene(bare)
     again = emu.GetMeshBVH(0)
     assert np.array_equal(again[0].view(np.uint32), trees[0][0].view(np.uint32)) and np.array_equal(again[1], trees[0][1])
+    # a scene with both kinds of mesh: the first keeps the tree it came with, the second gets one built on the device
+    c2 = Scene.load(scene_path("c2_mesh_room.xml"))
+    assert c2.desc.n_meshes == 2
+    mixed = c2.with_bvh({1: None})
+    emu.LoadScene(mixed)
+    kept, built = emu.GetMeshBVH(0), emu.GetMeshBVH(1)
+    m0 = c2.desc.meshes[0]
+    assert np.array_equal(kept[0].view(np.uint32), np.ctypeslib.as_array(C.cast(m0.bvh, C.POINTER(C.c_uint32)), shape=(m0.n_bvh_nodes * 8,)))
+    common_checks.assert_bvh_valid(built[0], built[1], c2.desc.meshes[1])
+    p = params(64, 36, spp=1, jitter=0, bounces=2)
+    g, c = emu.Render(p), oracle_ffi.OracleScene(c2.with_bvh({1: built})).render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
+    assert common_checks.rel_colour_diff(g.radiance, c.radiance) <= 1e-4
     # tiny meshes: one leaf, and a mesh of exactly 5 faces (one split); many faces with the same centre (equal codes)
     for n_faces, same in ((1, False), (4, False), (5, False), (40, True)):
         with open(tmp_path / f"tiny{n_faces}.obj", "w") as f:
