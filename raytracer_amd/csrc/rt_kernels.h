@@ -307,7 +307,7 @@ RT_KERNEL(k_raygen_trace, DScene S, PassP P, FrameBufs F, RayQ Q, MeshQ MQ) {
     // primary rays see front faces only (RayTracer.cpp:233)
     const CandSink K = cand_sink(MQ, seg % MQ.nseg, F.overflow);
     if (TLAS) { if (valid) closest_instances_tlas<CNT, true>(S, o, dir, 1, B, head, K, stk, stride, cnt); }
-    else closest_instances<CNT, true>(S, o, dir, 1, B, head, K, stk, stride, cnt, valid);   // (every lane: wave-wide appends)
+    else closest_instances<CNT, true, true>(S, o, dir, 1, B, head, K, stk, stride, cnt, valid);   // (every lane: wave-wide appends)
     if (valid && head == RT_NONE) write_raw(Q, qi, B);
     uint32_t wi = seg_push(valid && head != RT_NONE, MQ.counts, seg % MQ.nseg, MQ.segcap, F.overflow);
     if (wi != RT_NONE) {
