@@ -1141,6 +1141,74 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
   }
   return occluded;
 }
+// Can NO ray from P to a point within R of C be occluded?  (The rays of one soft-shadow group: PointLight::Illuminate's
+// disc samples lie within the light's size of its centre, lights.cpp:34-60, and a group whose first shadow_min rays are all
+// unoccluded is fully lit, :56-59 — for a group with a clear view of the whole light that is known without tracing them.)
+// Conservative, per instance, against what the per-ray tests would decide (any_instances):
+//   every point of such a ray lies within R of the segment P -> C (at the same fraction of the way), so an instance whose
+//   padded world box, grown by R, the segment misses cannot be hit;
+//   a plane (z = 0 in its own space, objects.cpp:152-167) cannot be hit when P and every end point lie on one side of it, or
+//   the crossing comes before the test's t > 0.0002 or after the light;
+//   a sphere (objects.cpp:63-82) cannot be hit when the segment stays farther than 1 + R from its centre;
+//   a mesh whose grown box the segment touches is taken to occlude.
+// `true` is a proof; `false` only means the rays have to be traced.  Every lane of the wave must call (wave-uniform loop
+// over the scalar-loaded instance table); `active`: this lane has a group.
+RT_DEV bool cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
+  RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
+  RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
+  const V3 a = C - P;
+  const float len = length(a);
+  bool clear = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
+  const V3 ainv = v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+  const float s_max = 1.0f + 1.01f * R / (len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
+  const float Rw = R * 1.002f + 1e-4f;
+  ParentRay pr;
+  pr.key = -2; pr.p = P; pr.d = a;
+  for (int i = 0; i < S.n_inst; i++) {
+    RT_UTYPE(DInstance)* I = inst + i;
+    float tm;
+    const bool touch = clear && box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw, I->wmax[1] + Rw,
+                                         I->wmax[2] + Rw, tm) && !(tm > s_max);
+    if (!wave_any(touch)) continue;   // [wave-uniform]
+    const int prim = I->prim;
+    if (prim == 3) {
+      if (touch) clear = false;
+      continue;
+    }
+    // the segment in the instance's space (the same transforms, in the same order, as the rays' own: P lands on the
+    // very floats the per-ray tests see), and a bound on how far R reaches there: R x the product of the levels'
+    // Frobenius norms
+    V3 p, d;
+    ray_to_instance(I, xf, P, a, pr, p, d);
+    float grow = 1.0f;
+    for (int k = 0; k < I->depth; k++) {
+      RT_UTYPE(float)* m = xf + I->xf_off + 24 * k;
+      grow *= sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + m[6] * m[6] + m[7] * m[7] + m[8] * m[8]);
+    }
+    const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+    const float Rl = R * grow * 1.002f + 1e-5f * (1.0f + mag);
+    bool free_of = false;
+    if (prim == 2) {
+      const float z0 = p.z;
+      const float wlo = d.z - Rl, whi = d.z + Rl;   // z of the rays' end points relative to P's
+      const float amin = wlo > 0.0f ? wlo : (whi < 0.0f ? -whi : 0.0f), amax = fmaxf(fabsf(wlo), fabsf(whi));
+      const bool same_side = (z0 >= 0.0f && wlo > 0.0f) || (z0 <= 0.0f && whi < 0.0f);
+      const bool too_near = amin >= fabsf(z0) * (len + R) * (1.01f / 0.0002f) + 1e-7f;   // t = |z0| / |d.z| <= 0.0002
+      const bool not_reached = amax <= 0.99f * fabsf(z0);                                // t >= t_max
+      free_of = same_side || too_near || not_reached;
+    } else {
+      const float dd = dot(d, d);
+      float sn = dd > 0.0f ? -dot(p, d) / dd : 0.0f;
+      sn = fminf(fmaxf(sn, 0.0f), s_max);
+      const V3 q = p + d * sn;
+      const float reach = 1.0f + Rl;
+      free_of = dot(q, q) > reach * reach * 1.001f;
+    }
+    if (touch && !free_of) clear = false;
+  }
+  return clear;
+}
+
 template <bool CNT>
 RT_DEV bool scene_any(const DScene& S, V3 o, V3 dir, float t_max, uint32_t* stk, uint32_t stride, Cnt<CNT>& cnt) {
   uint32_t head;

@@ -1159,10 +1159,38 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   if (CNT) cnt.flush(F.counters);
 }
 
-// early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues
-RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, uint32_t* list2, uint32_t* n2) {
+// Groups with a clear view of the whole light (cone_clear) are fully lit without a ray: their term is added here, as
+// k_shadow_soft_decide adds it for a group whose shadow_min rays all came through (vis = 1).  The others are listed for
+// the sample phases.
+template <bool CNT>
+RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_t* list1, uint32_t* n1) {
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
+    V3 Pp = v3(0, 0, 0), C = v3(0, 0, 1);
+    float R = 0.0f;
+    if (seg_valid) {
+      const float4 g0 = G.g0[g];
+      const DLight& L = S.lights[__float_as_uint(g0.w)];
+      Pp = v3(g0.x, g0.y, g0.z);
+      C = v3(L.position[0], L.position[1], L.position[2]);
+      R = G.g3[g].w;
+    }
+    const bool clear = cone_clear(S, Pp, C, R, seg_valid);
+    if (seg_valid && clear) {
+      const float4 g1 = G.g1[g];
+      add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * 1.0f);
+    }
+    uint32_t li = seg_push(seg_valid && !clear, n1, sw_.s, G.segcap, F.overflow);
+    if (li != RT_NONE) list1[li] = g;
+  RT_SEG_END
+}
+
+// early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues
+// (`list1`: the groups the first sample phase ran for; null = every group of the queue)
+RT_KERNEL(k_shadow_soft_decide, PassP P, FrameBufs F, GroupQ G, const uint32_t* list1, const uint32_t* n1, uint32_t* list2, uint32_t* n2) {
+  RT_SEG_BEGIN((list1 ? n1 : G.counts), G.nseg, G.segcap, 1u)
+    uint32_t g = seg_base_ + (uint32_t)seg_e;
+    if (list1 && seg_valid) g = list1[g];
     bool more = false;
     if (seg_valid) {
       uint32_t lit = __float_as_uint(G.g2[g].z);

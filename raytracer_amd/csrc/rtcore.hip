@@ -111,6 +111,7 @@ struct Options {
   double frame_gb = 0;             // "frame_gb"     RT_FRAME_GB      stage-queue memory of one pass (0: frame_mem_mb / 32 GB)
   double fan_scale = 1;            // "fan_scale"    RT_TEST_FAN_SCALE  scales the measured queue sizing (tests: forces overflow)
   double timing = 0;               // "timing"       RT_TIMING        host-side phases of the photon build on stderr
+  double soft_clear = 1;           // "soft_clear"   RT_SOFT_CLEAR    0: trace every soft-shadow group (tests compare both)
 };
 
 // grow-only device buffers the entry points reuse from call to call (no hipMalloc / hipFree in the steady state)
@@ -149,6 +150,7 @@ struct rt_context {
   GatherQ GQ;
   MeshQ MQ, MH, MS;
   uint32_t* d_list2 = nullptr;
+  uint32_t* d_list1 = nullptr;   // soft-shadow groups that have to be traced (k_shadow_soft_clear)
   uint32_t* d_gather_cursor = nullptr;  // GatherP::cursor, one slab per stage
   uint32_t* d_gather_retry = nullptr;   // GatherP::retry, retry_seed
   float* d_gather_seed = nullptr;
@@ -612,6 +614,7 @@ int rt_context_create(int device_id, rt_context** out) {
   env("RT_FRAME_GB", ctx->opt.frame_gb);
   env("RT_TEST_FAN_SCALE", ctx->opt.fan_scale);
   if (std::getenv("RT_TIMING")) ctx->opt.timing = 1;
+  if (const char* e = std::getenv("RT_SOFT_CLEAR")) ctx->opt.soft_clear = std::atof(e);
   *out = ctx;
   return RT_OK;
 }
@@ -625,6 +628,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "frame_gb") ctx->opt.frame_gb = value;
   else if (n == "fan_scale") { ctx->opt.fan_scale = value; ctx->fan_valid = false; }
   else if (n == "timing") ctx->opt.timing = value;
+  else if (n == "soft_clear") ctx->opt.soft_clear = value;
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
   return RT_OK;
 }
@@ -1074,7 +1078,8 @@ enum { CNT_Q = 0, CNT_GH = 1, CNT_GS = 2, CNT_N2 = 3, CNT_GQ = 4,
        CUR_MQ = 9, CUR_MH = 10, CUR_MS1 = 11, CUR_MS2 = 12,     // their claim cursors
        CNT_GR = 13,                                             // photon lookups left to the second gather stage
        CNT_CQ = 14, CNT_CH = 15, CNT_CS1 = 16, CNT_CS2 = 17,    // candidate lists of the mesh-phase items (MeshQ::cand)
-       CNT_KINDS = 18 };
+       CNT_N1 = 18,                                             // soft-shadow groups without a clear view of their light (k_shadow_soft_clear)
+       CNT_KINDS = 19 };
 constexpr int NFAN = 10;
 constexpr int MAX_LEVELS = 8;
 constexpr uint32_t NSEG = 64;
@@ -1600,6 +1605,8 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
   if ((rc = alloc_group(ctx->GS, fp.n_soft ? fp.f[2] : 0.0, true))) return rc;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.segcap * NSEG * 4, &p))) return rc;
   ctx->d_list2 = (uint32_t*)p;
+  if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)ctx->GS.segcap * NSEG * 4, &p))) return rc;
+  ctx->d_list1 = (uint32_t*)p;
   size_t gsegcap = fp.photons ? cap_of(fp.f[3]) : 1;
   ctx->GQ.segcap = (uint32_t)gsegcap;
   ctx->GQ.nseg = NSEG;
@@ -1739,13 +1746,19 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
       MeshQ MS1 = meshq(ctx->MS, lvl, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, lvl, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
+      // groups with a clear view of their whole light are fully lit without a ray (instance table walk only: scenes that
+      // use the instance BVH trace every group)
+      const bool clear_first = ctx->opt.soft_clear != 0 && !ctx->ds.use_tlas;
+      uint32_t* n1 = ctx->d_counts + cnt_at(lvl, CNT_N1);
+      const uint32_t* list1 = clear_first ? ctx->d_list1 : nullptr;
       {
         Timer t(ctx, RT_K_SHADOW);
+        if (clear_first) LAUNCH_P1((k_shadow_soft_clear<CNT>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
         if (ctx->ds.use_tlas)
           LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
                    (uint32_t)P.shadow_min, MS1);
         else
-          LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+          LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, list1, (const uint32_t*)(list1 ? n1 : nullptr), 0u,
                     (uint32_t)P.shadow_min, MS1);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GS));
       }
@@ -1754,7 +1767,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
         LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS1));
       }
-      LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, ctx->d_list2, n2);
+      LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, list1, (const uint32_t*)n1, ctx->d_list2, n2);
       if (P.shadow_max > P.shadow_min) {
         // The remaining samples of the groups that are not fully lit (lights.cpp:56-59).  With meshes in the scene they are
         // taken RT_SOFT_CHUNK samples at a time: every undecided ray is an item + candidates of the mesh phase (48 bytes),

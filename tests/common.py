@@ -465,6 +465,32 @@ def check_device_bvh(r, scene, w, h, n_rays):
     return trees, depths
 
 
+def check_soft_shadow_clear_view(r, scene, w, h, spp=1, tol=2e-6, min_saved=0.2, strict=None):
+    """Soft-shadow groups with a proven clear view of their whole light are finished without a ray (cone_clear): the
+    frame must be the one that traces every group (same groups, same terms; only the order of the float atomics on a
+    path's radiance differs), with the oracle as the third opinion, and the shortcut must actually save rays."""
+    import oracle_ffi
+    r.LoadScene(scene)
+    p = params(w, h, spp=spp, jitter=1, bounces=1, light_scale=1.0)
+    out = {}
+    for mode in (1, 0):
+        r.set_option("soft_clear", mode)
+        r.counters(enable=True, reset=True)
+        out[mode] = (r.Render(p), r.counters()["rays_shadow"])
+    r.counters(enable=False)
+    r.set_option("soft_clear", 1)
+    (g1, n1), (g0, n0) = out[1], out[0]
+    assert np.array_equal(g1.hit_node, g0.hit_node)
+    assert rel_colour_diff(g1.radiance, g0.radiance, floor=1e-2) <= tol, "the clear-view shortcut changed the frame"
+    assert n1 <= (1.0 - min_saved) * n0, f"no rays saved: {n1} vs {n0}"
+    c = oracle_ffi.OracleScene(scene).render(p)
+    if strict is not None:
+        assert rel_colour_diff(g1.radiance, c.radiance, floor=1e-2) <= strict
+    else:
+        assert_stochastic_close(g1, c, "clear-view soft shadows")
+    return n1, n0
+
+
 def check_reference_scene_fixtures(r, w, h, strict=None):
     """north_star: "every bundled scene renders within tolerance of the CPU reference".  tests/golden/scenes/ref_*.xml carry
     the scene data of eight bundled reference scenes (nested transforms, direct + ambient + soft point lights, reflection /

@@ -88,6 +88,13 @@ def test_stress_scene_scaled(emu):
     assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
 
 
+def test_soft_shadow_clear_view_shortcut(emu):
+    """Cornell box with a sphere light (nested transforms, planes and spheres) and the textured C3 scene."""
+    n1, n0 = common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("cornell_box.xml")), 64, 48, strict=1e-4)
+    print("cornell_box: shadow rays", n1, "of", n0)
+    common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("c3_cornell_textured.xml")), 48, 27, strict=1e-4)
+
+
 def test_device_bvh_build(emu, tmp_path):
     """Meshes without a tree get a linear BVH at rt_scene_commit (here: the same kernels under host emulation); a tree that
     comes with the mesh is handed back unchanged by rt_scene_mesh_bvh."""

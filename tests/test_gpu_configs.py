@@ -59,6 +59,17 @@ def test_c5_stress_scene_scaled(gpu_renderer):
     print("c5 scaled:", cc.assert_stochastic_close(g, c, "stress scene"))
 
 
+def test_soft_shadow_clear_view_shortcut(gpu_renderer):
+    """Soft-shadow groups with a proven clear view of the light are fully lit without tracing (cone_clear): same frame as
+    with every group traced, oracle parity, and fewer rays — on the Cornell box, C3's scene and the scaled stress scene
+    (one big mesh: no group can be cleared, nothing may change)."""
+    for name, w, h in (("cornell_box.xml", 320, 240), ("c3_cornell_textured.xml", 320, 180)):
+        n1, n0 = cc.check_soft_shadow_clear_view(gpu_renderer, Scene.load(scene_path(name)), w, h, spp=2, tol=1e-5)
+        print(name, "shadow rays", n1, "of", n0)
+    stress = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
+    cc.check_soft_shadow_clear_view(gpu_renderer, stress, 160, 90, tol=1e-5, min_saved=-1.0)
+
+
 def test_device_bvh_build(gpu_renderer):
     """n2: meshes without a tree get a linear BVH on the device at rt_scene_commit (rt_bvh_build.h): a valid BVH of the mesh,
     and with the oracle walking the SAME tree (rt_scene_mesh_bvh) node + face ids are bit-exact and the batched closest /
