@@ -1141,24 +1141,36 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
   }
   return occluded;
 }
-// Can NO ray from P to a point within R of C be occluded?  (The rays of one soft-shadow group: PointLight::Illuminate's
-// disc samples lie within the light's size of its centre, lights.cpp:34-60, and a group whose first shadow_min rays are all
-// unoccluded is fully lit, :56-59 — for a group with a clear view of the whole light that is known without tracing them.)
-// Conservative, per instance, against what the per-ray tests would decide (any_instances):
-//   every point of such a ray lies within R of the segment P -> C (at the same fraction of the way), so an instance whose
-//   padded world box, grown by R, the segment misses cannot be hit;
-//   a plane (z = 0 in its own space, objects.cpp:152-167) cannot be hit when P and every end point lie on one side of it, or
-//   the crossing comes before the test's t > 0.0002 or after the light;
-//   a sphere (objects.cpp:63-82) cannot be hit when the segment stays farther than 1 + R from its centre;
-//   a mesh whose grown box the segment touches is taken to occlude.
-// `true` is a proof; `false` only means the rays have to be traced.  Every lane of the wave must call (wave-uniform loop
-// over the scalar-loaded instance table); `active`: this lane has a group.
-RT_DEV bool cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
+// What can be said about the rays from P to the points within R of C without tracing them?  (The rays of one soft-shadow
+// group: PointLight::Illuminate's disc samples lie within the light's size of its centre, lights.cpp:34-60; a group whose
+// first shadow_min rays are all unoccluded is fully lit, :56-59, and one whose every ray is occluded sums to nothing, :66.)
+//   RT_CONE_CLEAR  no ray can be occluded: the group is fully lit;
+//   RT_CONE_UMBRA  every ray is occluded (by one sphere): the group contributes nothing;
+//   RT_CONE_TRACE  neither is proven.
+// Conservative, per instance, against what the per-ray tests would decide (any_instances).  Every point of such a ray lies
+// within s R of the point at fraction s of the segment P -> C, and its direction within asin(R / |C - P|) of the segment's.
+//   clear of an instance: the segment misses its padded world box grown by R;
+//     a plane (z = 0 in its own space, objects.cpp:152-167) when P and every end point lie on one side of it, or the crossing
+//     comes before the test's t > 0.0002 or after the light;
+//     a sphere (objects.cpp:63-82) when the segment stays farther from its centre than 1 + the cone's radius there, or when
+//     P lies on or outside it and every ray moves away from the centre (the sphere P itself is on: the far root is <= 0,
+//     or below the test's t > 0.01 when rounding left P just inside);
+//     a mesh whose grown box the segment touches is taken to occlude.
+//   umbra of a sphere: every direction of the cone lies inside the sphere's outline seen from P, the sphere begins more
+//     than the test's 0.01 away and before the light; or P lies on the sphere, every ray enters it and leaves it again
+//     between 0.01 and the light (the far side of the sphere P itself is on).
+// RT_CONE_CLEAR / RT_CONE_UMBRA are proofs.  Every lane of the wave must call (wave-uniform loop over the scalar-loaded
+// instance table); `active`: this lane has a group.
+#define RT_CONE_TRACE 0
+#define RT_CONE_CLEAR 1
+#define RT_CONE_UMBRA 2
+RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   const V3 a = C - P;
   const float len = length(a);
-  bool clear = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
+  const bool sized = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
+  bool clear = sized, umbra = false;
   const V3 ainv = v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
   const float s_max = 1.0f + 1.01f * R / (len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
   const float Rw = R * 1.002f + 1e-4f;
@@ -1167,26 +1179,31 @@ RT_DEV bool cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     float tm;
-    const bool touch = clear && box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw, I->wmax[1] + Rw,
-                                         I->wmax[2] + Rw, tm) && !(tm > s_max);
-    if (!wave_any(touch)) continue;   // [wave-uniform]
+    const bool touch = sized && !umbra && box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw, I->wmax[1] + Rw,
+                                                   I->wmax[2] + Rw, tm) && !(tm > s_max);
     const int prim = I->prim;
+    if (!wave_any(touch && (clear || prim == 1))) continue;   // [wave-uniform]
     if (prim == 3) {
       if (touch) clear = false;
       continue;
     }
     // the segment in the instance's space (the same transforms, in the same order, as the rays' own: P lands on the
     // very floats the per-ray tests see), and a bound on how far R reaches there: R x the product of the levels'
-    // Frobenius norms
+    // largest stretch (Gershgorin bound on M M^T: exact for rotation x uniform scale)
     V3 p, d;
     ray_to_instance(I, xf, P, a, pr, p, d);
     float grow = 1.0f;
     for (int k = 0; k < I->depth; k++) {
       RT_UTYPE(float)* m = xf + I->xf_off + 24 * k;
-      grow *= sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + m[6] * m[6] + m[7] * m[7] + m[8] * m[8]);
+      const float g00 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], g11 = m[3] * m[3] + m[4] * m[4] + m[5] * m[5], g22 = m[6] * m[6] + m[7] * m[7] + m[8] * m[8];
+      const float g01 = fabsf(m[0] * m[3] + m[1] * m[4] + m[2] * m[5]), g02 = fabsf(m[0] * m[6] + m[1] * m[7] + m[2] * m[8]),
+                  g12 = fabsf(m[3] * m[6] + m[4] * m[7] + m[5] * m[8]);
+      grow *= sqrtf(fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22))) * 1.0001f;
     }
     const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
-    const float Rl = R * grow * 1.002f + 1e-5f * (1.0f + mag);
+    const float slack = 1e-5f * (1.0f + mag);
+    const float Rg = R * grow * 1.002f;   // the cone's radius at the light, in this space
+    const float Rl = Rg + slack;
     bool free_of = false;
     if (prim == 2) {
       const float z0 = p.z;
@@ -1197,16 +1214,44 @@ RT_DEV bool cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
       const bool not_reached = amax <= 0.99f * fabsf(z0);                                // t >= t_max
       free_of = same_side || too_near || not_reached;
     } else {
-      const float dd = dot(d, d);
-      float sn = dd > 0.0f ? -dot(p, d) / dd : 0.0f;
+      const float dd = dot(d, d), pd = dot(p, d), pp = dot(p, p);
+      const float dl = sqrtf(dd), pl = sqrtf(pp), c = pp - 1.0f;
+      const float wmax = dl + Rl, wmin = dl - Rl;   // lengths of the rays here (s = 1 at their light sample)
+      // the cone's radius where it could touch: no farther along than where the axis leaves the sphere grown by the
+      // radius at the far end
+      float sn = dd > 0.0f ? -pd / dd : 0.0f;
       sn = fminf(fmaxf(sn, 0.0f), s_max);
-      const V3 q = p + d * sn;
-      const float reach = 1.0f + Rl;
-      free_of = dot(q, q) > reach * reach * 1.001f;
+      const float reach0 = 1.0f + s_max * Rg + slack;
+      const V3 q0 = p + d * sn;
+      bool beyond = dot(q0, q0) > reach0 * reach0 * 1.001f;
+      if (!beyond && dd > 0.0f) {
+        const float disc = pd * pd - dd * (pp - reach0 * reach0);
+        float s_hi = disc > 0.0f ? (-pd + sqrtf(disc)) / dd * 1.001f + 1e-6f : s_max;
+        s_hi = fminf(fmaxf(s_hi, 0.0f), s_max);
+        const float reach1 = 1.0f + s_hi * Rg + slack;
+        const V3 q1 = p + d * fminf(sn, s_hi);
+        beyond = dot(q1, q1) > reach1 * reach1 * 1.001f;
+      }
+      // P on or outside the sphere and every ray moving away from its centre
+      const float bmin = pd - Rl * pl * 1.01f;
+      const bool leaving = bmin > 0.0f && (c >= 0.0f || (-c * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
+      free_of = beyond || leaving;
+      if (touch && wmin > 0.0f) {
+        const float sin_a = Rl * 1.01f / dl;
+        // (b) another sphere in front of the whole light
+        const V3 cr = cross(p, d);
+        const float sin_f = sqrtf(dot(cr, cr)) / (pl * dl);
+        const bool covers = pd < 0.0f && pl > 1.0f && (sin_f + sin_a) * pl < 0.99f && (pl - 1.0f) * (len - R) > 0.02f * wmax && pl < 0.99f * wmin;
+        // (a) the sphere P is on, rays going in: the far root 2 |p.w| / w.w, bounded from both sides
+        const float bneg = -(pd + Rl * pl * 1.01f), bpos = -pd + Rl * pl * 1.01f;
+        const bool through = bneg > 0.0f && fabsf(c) * wmax * wmax <= 0.01f * bneg * bneg && 1.99f * bneg * (len - R) > 0.02f * wmax * wmax &&
+                             2.01f * bpos < 0.99f * wmin * wmin;
+        if (covers || through) umbra = true;
+      }
     }
     if (touch && !free_of) clear = false;
   }
-  return clear;
+  return umbra ? RT_CONE_UMBRA : (clear ? RT_CONE_CLEAR : RT_CONE_TRACE);
 }
 
 template <bool CNT>

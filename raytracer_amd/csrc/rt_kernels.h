@@ -1160,8 +1160,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
 }
 
 // Groups with a clear view of the whole light (cone_clear) are fully lit without a ray: their term is added here, as
-// k_shadow_soft_decide adds it for a group whose shadow_min rays all came through (vis = 1).  The others are listed for
-// the sample phases.
+// k_shadow_soft_decide adds it for a group whose shadow_min rays all came through (vis = 1).  Groups in the full shadow of
+// a sphere contribute vis = 0 (k_shadow_soft_final's 0 / shadow_max): nothing is added.  The others are listed for the
+// sample phases.
 template <bool CNT>
 RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_t* list1, uint32_t* n1) {
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
@@ -1175,12 +1176,12 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
       C = v3(L.position[0], L.position[1], L.position[2]);
       R = G.g3[g].w;
     }
-    const bool clear = cone_clear(S, Pp, C, R, seg_valid);
-    if (seg_valid && clear) {
+    const int view = cone_clear(S, Pp, C, R, seg_valid);
+    if (seg_valid && view == RT_CONE_CLEAR) {
       const float4 g1 = G.g1[g];
       add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * 1.0f);
     }
-    uint32_t li = seg_push(seg_valid && !clear, n1, sw_.s, G.segcap, F.overflow);
+    uint32_t li = seg_push(seg_valid && view == RT_CONE_TRACE, n1, sw_.s, G.segcap, F.overflow);
     if (li != RT_NONE) list1[li] = g;
   RT_SEG_END
 }

@@ -93,6 +93,7 @@ def test_soft_shadow_clear_view_shortcut(emu):
     n1, n0 = common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("cornell_box.xml")), 64, 48, strict=1e-4)
     print("cornell_box: shadow rays", n1, "of", n0)
     common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("c3_cornell_textured.xml")), 48, 27, strict=1e-4)
+    print("random scene graphs: shadow rays %d of %d" % common_checks.check_soft_shadow_clear_view_random(emu, range(4, 10), 64, 48, strict=1e-4))
 
 
 def test_device_bvh_build(emu, tmp_path):

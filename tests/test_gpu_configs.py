@@ -60,12 +60,14 @@ def test_c5_stress_scene_scaled(gpu_renderer):
 
 
 def test_soft_shadow_clear_view_shortcut(gpu_renderer):
-    """Soft-shadow groups with a proven clear view of the light are fully lit without tracing (cone_clear): same frame as
-    with every group traced, oracle parity, and fewer rays — on the Cornell box, C3's scene and the scaled stress scene
-    (one big mesh: no group can be cleared, nothing may change)."""
+    """Soft-shadow groups with a proven clear view of the light are fully lit, and groups in the full shadow of a sphere dark,
+    without tracing (cone_clear): same frame as with every group traced, oracle parity, and fewer rays — on the Cornell box,
+    C3's scene, random nested scene graphs and the scaled stress scene (one big mesh: no group can be cleared, nothing may
+    change)."""
     for name, w, h in (("cornell_box.xml", 320, 240), ("c3_cornell_textured.xml", 320, 180)):
         n1, n0 = cc.check_soft_shadow_clear_view(gpu_renderer, Scene.load(scene_path(name)), w, h, spp=2, tol=1e-5)
         print(name, "shadow rays", n1, "of", n0)
+    print("random scene graphs: shadow rays %d of %d" % cc.check_soft_shadow_clear_view_random(gpu_renderer, range(0, 12), 160, 120, tol=1e-5))
     stress = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
     cc.check_soft_shadow_clear_view(gpu_renderer, stress, 160, 90, tol=1e-5, min_saved=-1.0)
 
