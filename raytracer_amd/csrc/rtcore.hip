@@ -61,6 +61,9 @@
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 8   // streaming kernels: measured 4 -> 8 blocks per CU: k_shade 5.8 -> 4.8 ms per bench step
 #endif
+#ifndef RT_CONE_MAX_INST
+#define RT_CONE_MAX_INST 256   // soft-shadow proofs (cone_clear) walk the instance table linearly
+#endif
 #ifndef RT_TLAS_MIN
 #define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
 #endif
@@ -1746,16 +1749,17 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       uint64_t gs_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GS.segcap * GS.nseg);
       MeshQ MS1 = meshq(ctx->MS, lvl, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, lvl, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
-      // groups with a clear view of their whole light are fully lit without a ray (instance table walk only: scenes that
-      // use the instance BVH trace every group)
-      const bool clear_first = ctx->opt.soft_clear != 0 && !ctx->ds.use_tlas;
+      // groups with a clear view of their whole light are fully lit, groups in a sphere's full shadow dark, without a ray
+      // (the proof walks the instance table: one box test per instance for most; scenes of more than RT_CONE_MAX_INST
+      // instances trace every group)
+      const bool clear_first = ctx->opt.soft_clear != 0 && ctx->ds.n_inst <= RT_CONE_MAX_INST;
       uint32_t* n1 = ctx->d_counts + cnt_at(lvl, CNT_N1);
       const uint32_t* list1 = clear_first ? ctx->d_list1 : nullptr;
       {
         Timer t(ctx, RT_K_SHADOW);
         if (clear_first) LAUNCH_P1((k_shadow_soft_clear<CNT>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
         if (ctx->ds.use_tlas)
-          LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+          LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, list1, (const uint32_t*)(list1 ? n1 : nullptr), 0u,
                    (uint32_t)P.shadow_min, MS1);
         else
           LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, list1, (const uint32_t*)(list1 ? n1 : nullptr), 0u,
