@@ -45,8 +45,11 @@ struct DInstance {      // a node that carries a primitive (64 bytes); its chain
   int32_t depth;        // levels in the chain root .. this node
   int32_t parent_key;   // node index of the parent (identifies the chain prefix), -1 for a root-level instance
   int32_t xf_off;       // float offset into DScene::xf of this instance's chain: depth x { itm[12], tm[12] }, root first
-  uint32_t shade_base;  // mesh instances: index of the mesh's first face record in DScene::shade (copied from the mesh so
-                        // that the shading attributes are one fetch away from the instance record)
+  union {
+    uint32_t shade_base;  // mesh instances: index of the mesh's first face record in DScene::shade (copied from the mesh so
+                          // that the shading attributes are one fetch away from the instance record)
+    float stretch;        // spheres and planes: how far a unit world length can reach in the instance's space (chain_stretch)
+  };
   float wmin[3];        // padded world-space bounds (culling of mesh instances only)
   uint32_t has_uvw;     // mesh instances: the mesh has texture coordinates
   float wmax[3];
@@ -1161,6 +1164,28 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
 //     between 0.01 and the light (the far side of the sphere P itself is on).
 // RT_CONE_CLEAR / RT_CONE_UMBRA are proofs.  Every lane of the wave must call (wave-uniform loop over the scalar-loaded
 // instance table); `active`: this lane has a group.
+// Upper bound on |M v| / |v| over a chain of world -> local 3 x 3 parts (`itm`, 24 floats apart, root first): per level the
+// square root of the largest row sum of |M M^T| (Gershgorin; exact for rotation x uniform scale), a hair up for rounding.
+RT_HD float chain_stretch(const float* itm, int depth) {
+  float grow = 1.0f;
+  for (int k = 0; k < depth; k++) {
+    const float* m = itm + 24 * k;
+    const float g00 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], g11 = m[3] * m[3] + m[4] * m[4] + m[5] * m[5], g22 = m[6] * m[6] + m[7] * m[7] + m[8] * m[8];
+    const float g01 = fabsf(m[0] * m[3] + m[1] * m[4] + m[2] * m[5]), g02 = fabsf(m[0] * m[6] + m[1] * m[7] + m[2] * m[8]),
+                g12 = fabsf(m[3] * m[6] + m[4] * m[7] + m[5] * m[8]);
+    grow *= sqrtf(fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22))) * 1.0001f;
+  }
+  return grow;
+}
+// v_rcp_f32 / v_sqrt_f32 (1 ulp) for bounds that carry margins of 1e-3 and more: the correctly rounded forms cost ten
+// instructions each, and cone_clear is bound by VALU issue
+#ifndef RT_EMU
+RT_DEV float rt_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV float rt_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+RT_DEV float rt_fast_rcp(float x) { return 1.0f / x; }
+RT_DEV float rt_fast_sqrt(float x) { return sqrtf(x); }
+#endif
 #define RT_CONE_TRACE 0
 #define RT_CONE_CLEAR 1
 #define RT_CONE_UMBRA 2
@@ -1168,11 +1193,11 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   const V3 a = C - P;
-  const float len = length(a);
+  const float len = rt_fast_sqrt(dot(a, a));
   const bool sized = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
   bool clear = sized, umbra = false;
-  const V3 ainv = v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
-  const float s_max = 1.0f + 1.01f * R / (len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
+  const V3 ainv = v3(rt_fast_rcp(a.x), rt_fast_rcp(a.y), rt_fast_rcp(a.z));
+  const float s_max = 1.0f + 1.01f * R * rt_fast_rcp(len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
   const float Rw = R * 1.002f + 1e-4f;
   ParentRay pr;
   pr.key = -2; pr.p = P; pr.d = a;
@@ -1188,18 +1213,10 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
       continue;
     }
     // the segment in the instance's space (the same transforms, in the same order, as the rays' own: P lands on the
-    // very floats the per-ray tests see), and a bound on how far R reaches there: R x the product of the levels'
-    // largest stretch (Gershgorin bound on M M^T: exact for rotation x uniform scale)
+    // very floats the per-ray tests see), and a bound on how far R reaches there (chain_stretch, computed at commit)
     V3 p, d;
     ray_to_instance(I, xf, P, a, pr, p, d);
-    float grow = 1.0f;
-    for (int k = 0; k < I->depth; k++) {
-      RT_UTYPE(float)* m = xf + I->xf_off + 24 * k;
-      const float g00 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], g11 = m[3] * m[3] + m[4] * m[4] + m[5] * m[5], g22 = m[6] * m[6] + m[7] * m[7] + m[8] * m[8];
-      const float g01 = fabsf(m[0] * m[3] + m[1] * m[4] + m[2] * m[5]), g02 = fabsf(m[0] * m[6] + m[1] * m[7] + m[2] * m[8]),
-                  g12 = fabsf(m[3] * m[6] + m[4] * m[7] + m[5] * m[8]);
-      grow *= sqrtf(fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22))) * 1.0001f;
-    }
+    const float grow = I->stretch;
     const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
     const float slack = 1e-5f * (1.0f + mag);
     const float Rg = R * grow * 1.002f;   // the cone's radius at the light, in this space
@@ -1215,18 +1232,19 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
       free_of = same_side || too_near || not_reached;
     } else {
       const float dd = dot(d, d), pd = dot(p, d), pp = dot(p, p);
-      const float dl = sqrtf(dd), pl = sqrtf(pp), c = pp - 1.0f;
+      const float dl = rt_fast_sqrt(dd), pl = rt_fast_sqrt(pp), c = pp - 1.0f;
+      const float inv_dd = rt_fast_rcp(dd), inv_dl = rt_fast_rcp(dl);
       const float wmax = dl + Rl, wmin = dl - Rl;   // lengths of the rays here (s = 1 at their light sample)
       // the cone's radius where it could touch: no farther along than where the axis leaves the sphere grown by the
       // radius at the far end
-      float sn = dd > 0.0f ? -pd / dd : 0.0f;
+      float sn = dd > 0.0f ? -pd * inv_dd : 0.0f;
       sn = fminf(fmaxf(sn, 0.0f), s_max);
       const float reach0 = 1.0f + s_max * Rg + slack;
       const V3 q0 = p + d * sn;
       bool beyond = dot(q0, q0) > reach0 * reach0 * 1.001f;
       if (!beyond && dd > 0.0f) {
         const float disc = pd * pd - dd * (pp - reach0 * reach0);
-        float s_hi = disc > 0.0f ? (-pd + sqrtf(disc)) / dd * 1.001f + 1e-6f : s_max;
+        float s_hi = disc > 0.0f ? (-pd + rt_fast_sqrt(disc)) * inv_dd * 1.001f + 1e-6f : s_max;
         s_hi = fminf(fmaxf(s_hi, 0.0f), s_max);
         const float reach1 = 1.0f + s_hi * Rg + slack;
         const V3 q1 = p + d * fminf(sn, s_hi);
@@ -1237,11 +1255,11 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
       const bool leaving = bmin > 0.0f && (c >= 0.0f || (-c * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
       free_of = beyond || leaving;
       if (touch && wmin > 0.0f) {
-        const float sin_a = Rl * 1.01f / dl;
+        const float sin_a = Rl * 1.01f * inv_dl;
         // (b) another sphere in front of the whole light
         const V3 cr = cross(p, d);
-        const float sin_f = sqrtf(dot(cr, cr)) / (pl * dl);
-        const bool covers = pd < 0.0f && pl > 1.0f && (sin_f + sin_a) * pl < 0.99f && (pl - 1.0f) * (len - R) > 0.02f * wmax && pl < 0.99f * wmin;
+        const float sin_f = rt_fast_sqrt(dot(cr, cr)) * inv_dl * 1.0001f;   // (x |p| below: sin f |p| against 0.99)
+        const bool covers = pd < 0.0f && pl > 1.0f && sin_f + sin_a * pl < 0.99f && (pl - 1.0f) * (len - R) > 0.02f * wmax && pl < 0.99f * wmin;
         // (a) the sphere P is on, rays going in: the far root 2 |p.w| / w.w, bounded from both sides
         const float bneg = -(pd + Rl * pl * 1.01f), bpos = -pd + Rl * pl * 1.01f;
         const bool through = bneg > 0.0f && fabsf(c) * wmax * wmax <= 0.01f * bneg * bneg && 1.99f * bneg * (len - R) > 0.02f * wmax * wmax &&

@@ -707,6 +707,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       xf.insert(xf.end(), cn.itm.m, cn.itm.m + 12);
       xf.insert(xf.end(), cn.tm.m, cn.tm.m + 12);
     }
+    if (I.prim != RT_PRIM_MESH) I.stretch = chain_stretch(xf.data() + I.xf_off, d);   // (shares the word with a mesh instance's shade_base)
     // padded world bounds (only mesh instances are culled with them)
     double lo[3], hi[3];
     if (n.prim_kind == RT_PRIM_MESH) {
@@ -880,7 +881,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       DShadeInst& R = sinst[i];
       std::memset(&R, 0, sizeof R);
       R.prim = inst[i].prim; R.node = inst[i].node; R.depth = inst[i].depth; R.xf_off = inst[i].xf_off;
-      R.shade_base = inst[i].shade_base; R.has_uvw = inst[i].has_uvw;
+      R.shade_base = inst[i].prim == RT_PRIM_MESH ? inst[i].shade_base : 0u; R.has_uvw = inst[i].has_uvw;
       R.mtl = mtls[inst[i].mtl];
     }
     if ((rc = upload(ctx, ctx->scene_mem, sinst, &D.sinst))) return rc;
