@@ -437,6 +437,10 @@ def main():
                        "scene_load_s": round(scene_load_s, 3), "scene_commit_s": round(scene_commit_s, 3),
                        "rays_per_step_per_gpu": rays_per_step, "paths_per_step_per_gpu": cnt["paths"],
                        "mpaths_per_s": cnt["paths"] * world * args.steps / dt / 1e6,
+                       # soft-shadow groups whose outcome is proven are finished without their rays: `value` counts
+                       # only rays that were traced; with the rays the reference traces for the same frame it would be
+                       "rays_proven_per_step_per_gpu": cnt["rays_shadow_proven"],
+                       "reference_equivalent_mrays_s": (rays_per_step + cnt["rays_shadow_proven"]) * world * args.steps / dt / 1e6,
                        "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,

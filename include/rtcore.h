@@ -225,6 +225,9 @@ typedef struct rt_counters {
   uint64_t closest_inst_tests, closest_node_visits, closest_tri_tests;
   /* mesh instances entered, mesh work items and rays finished by the second (mesh) phase of the closest-hit kernels */
   uint64_t mesh_inst_tests, mesh_items;
+  /* shadow rays the reference traces (lights.cpp:34-66) and this library did not have to: soft-shadow groups with a proven
+   * clear view of their light (shadow_min each) or proven to lie in full shadow (shadow_max each); not part of rays_shadow */
+  uint64_t rays_shadow_proven;
 } rt_counters;
 
 /* RT_K_TRACE_CLOSEST / RT_K_SHADOW: first phase (instance table: spheres, planes, mesh world boxes);

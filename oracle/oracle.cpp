@@ -213,6 +213,7 @@ struct Counters {
     c->plane_tests = plane_tests; c->node_visits = node_visits; c->tri_tests = tri_tests; c->shades = shades;
     c->tex_evals = tex_evals; c->photon_visits = photon_visits; c->gathers = gathers; c->paths = paths;
     c->closest_inst_tests = c->closest_node_visits = c->closest_tri_tests = 0;
+    c->rays_shadow_proven = 0;   // (every ray is traced here)
   }
 };
 

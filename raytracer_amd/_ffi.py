@@ -116,7 +116,8 @@ class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("rays_primary", "rays_secondary", "rays_shadow", "rays_photon", "inst_tests", "sphere_tests",
                  "plane_tests", "node_visits", "tri_tests", "shades", "tex_evals", "photon_visits", "gathers", "paths",
-                 "closest_inst_tests", "closest_node_visits", "closest_tri_tests", "mesh_inst_tests", "mesh_items")]
+                 "closest_inst_tests", "closest_node_visits", "closest_tri_tests", "mesh_inst_tests", "mesh_items",
+                 "rays_shadow_proven")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

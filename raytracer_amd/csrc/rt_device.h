@@ -148,6 +148,7 @@ struct DCounters {  // mirrors rt_counters
   unsigned long long shades, tex_evals, photon_visits, gathers, paths;
   unsigned long long closest_inst_tests, closest_node_visits, closest_tri_tests;
   unsigned long long mesh_inst_tests, mesh_items;
+  unsigned long long rays_shadow_proven;
 };
 
 // per-lane work counters kept in registers by the counted kernel variants

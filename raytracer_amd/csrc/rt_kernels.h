@@ -558,14 +558,20 @@ struct ShadePt {
   int sample;
 };
 
+// fmodf(u, 1.0f) for 0 <= u < 2 (a table entry in [0, 1) plus an offset in [0, 1)), bit for bit: u - 1 is exact there
+// (the library's fmodf is a reduction loop of about a hundred instructions)
+RT_DEV float wrap01(float u) { return u >= 1.0f ? u - 1.0f : u; }
+
 // glossy half vector, materials.cpp:35-49 / 79-94
 RT_DEV V3 gloss_half(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta, bool renorm) {
   int gi = sp.sample < S.n_gloss ? sp.sample : S.n_gloss - 1;
-  float phi = two_pi_times(fmodf(S.halton[RT_HGLOSS + gi] + oPhi, 1.0f));
-  float cosTheta = powf(fmodf(S.halton[RT_HGLOSS + S.n_gloss + gi] + oTheta, 1.0f), 1.0f / (gloss + 1.0f));
+  float phi = two_pi_times(wrap01(S.halton[RT_HGLOSS + gi] + oPhi));
+  float cosTheta = powf(wrap01(S.halton[RT_HGLOSS + S.n_gloss + gi] + oTheta), 1.0f / (gloss + 1.0f));
   float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
-  float x = sinTheta * cosf(phi);
-  float y = sinTheta * sinf(phi);
+  float sn, cs;
+  sincosf(phi, &sn, &cs);   // (one argument reduction for both)
+  float x = sinTheta * cs;
+  float y = sinTheta * sn;
   float z = cosTheta;
   V3 t, b;
   orthonormals(sp.N, t, b);
@@ -835,11 +841,13 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
             if (nonzero(wc)) {
               if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
               int hi = (sp.sample * P.mc_samples) % 1000;
-              float u1 = fmodf(S.halton[RT_HPHI + hi] + r1[2], 1.0f);
-              float u2 = fmodf(S.halton[RT_HTHETA + hi] + r1[3], 1.0f);
+              float u1 = wrap01(S.halton[RT_HPHI + hi] + r1[2]);
+              float u2 = wrap01(S.halton[RT_HTHETA + hi] + r1[3]);
               float r = sqrtf(u1);
               float phi = two_pi_times(u2);
-              float x = r * cosf(phi), y = r * sinf(phi), zz = sqrtf(1.0f - u1);
+              float sn, cs;
+              sincosf(phi, &sn, &cs);
+              float x = r * cs, y = r * sn, zz = sqrtf(1.0f - u1);
               V3 t, b;
               orthonormals(sp.N, t, b);
               c_mc.d = normalized((x * t) + (y * b) + (zz * sp.N));
@@ -1165,6 +1173,7 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
 // sample phases.
 template <bool CNT>
 RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_t* list1, uint32_t* n1) {
+  uint32_t proven = 0;
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
     V3 Pp = v3(0, 0, 0), C = v3(0, 0, 1);
@@ -1181,9 +1190,11 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
       const float4 g1 = G.g1[g];
       add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * 1.0f);
     }
+    if (CNT && seg_valid) proven += view == RT_CONE_CLEAR ? (uint32_t)P.shadow_min : (view == RT_CONE_UMBRA ? (uint32_t)(P.shadow_max > P.shadow_min ? P.shadow_max : P.shadow_min) : 0u);
     uint32_t li = seg_push(seg_valid && view == RT_CONE_TRACE, n1, sw_.s, G.segcap, F.overflow);
     if (li != RT_NONE) list1[li] = g;
   RT_SEG_END
+  if (CNT && proven) rt_atomic_add_u64(&F.counters->rays_shadow_proven, proven);
 }
 
 // early-out rule (lights.cpp:56-59): fully lit after shadow_min samples => done, else the group continues

@@ -478,10 +478,14 @@ def check_soft_shadow_clear_view(r, scene, w, h, spp=1, tol=2e-6, min_saved=0.2,
     for mode in (1, 0):
         r.set_option("soft_clear", mode)
         r.counters(enable=True, reset=True)
-        out[mode] = (r.Render(p), r.counters()["rays_shadow"])
+        g = r.Render(p)
+        cnt = r.counters()
+        out[mode] = (g, cnt["rays_shadow"], cnt["rays_shadow_proven"])
     r.counters(enable=False)
     r.set_option("soft_clear", 1)
-    (g1, n1), (g0, n0) = out[1], out[0]
+    (g1, n1, proven), (g0, n0, none) = out[1], out[0]
+    # a proven group stands for exactly the rays it would have traced: shadow_min (clear view) or shadow_max (full shadow)
+    assert none == 0 and n1 + proven == n0, f"traced {n1} + proven {proven} != {n0}"
     assert np.array_equal(g1.hit_node, g0.hit_node)
     assert rel_colour_diff(g1.radiance, g0.radiance, floor=1e-2) <= tol, "the clear-view shortcut changed the frame"
     assert n1 <= (1.0 - min_saved) * n0, f"no rays saved: {n1} vs {n0}"
