@@ -97,7 +97,8 @@ struct DShadeInst {     // what k_shade needs of a hit instance in ONE record: t
   int32_t prim, node;   // of its material, so that the material is not a second dependent fetch behind the instance
   int32_t depth, xf_off;
   uint32_t shade_base, has_uvw;
-  uint32_t pad_[2];
+  uint32_t uses_uvw;    // the material reads a texture map somewhere: only then are texture coordinates worth computing
+  uint32_t pad_;
   DMaterial mtl;
   uint32_t pad2_;
 };
@@ -963,6 +964,10 @@ RT_DEV bool any_instances_tlas(const DScene& S, V3 o, V3 dir, float t_max, uint3
 
 // Hit attributes of the winner (objects.cpp:37-43, 135-138, 303-320), Node::FromNodeCoords back up the chain
 // (scene.h:184-189), then the renderable lights (RayTracer.cpp:413-432).
+// Texture coordinates are part of the hit the batched queries hand back; k_shade only reads them through a texture map
+// (a sphere's cost atan2f, asinf and two double divisions, a mesh's two more 16-byte fetches per hit).
+RT_DEV bool wants_uvw(const DInstance&) { return true; }
+RT_DEV bool wants_uvw(const DShadeInst& I) { return I.uses_uvw != 0; }
 template <class InstT>   // DInstance, or k_shade's DShadeInst (same field names)
 RT_DEV bool finalize_hit_from(const DScene& S, const InstT* table, V3 o, V3 dir, const Best& B, Hit& hit) {
   const float best_t = B.t;
@@ -985,9 +990,12 @@ RT_DEV bool finalize_hit_from(const DScene& S, const InstT* table, V3 o, V3 dir,
     if (I.prim == 1) {  // objects.cpp:37-43
       hp = p + (d * best_t);
       hn = normalized(hp);
-      float tu = (float)(((double)atan2f(hp.y, hp.x) / (2 * RT_PI_D)) + .5);
-      float tv = (float)((double)asinf(hp.z) / RT_PI_D + .5);
-      uvw = v3(tu, tv, 0.0f);
+      uvw = v3(0.5f, 0.5f, 0.0f);
+      if (wants_uvw(I)) {
+        float tu = (float)(((double)atan2f(hp.y, hp.x) / (2 * RT_PI_D)) + .5);
+        float tv = (float)((double)asinf(hp.z) / RT_PI_D + .5);
+        uvw = v3(tu, tv, 0.0f);
+      }
     } else if (I.prim == 2) {  // objects.cpp:135-138
       hp = p + (d * best_t);
       hn = v3(0.0f, 0.0f, 1.0f);
@@ -997,7 +1005,7 @@ RT_DEV bool finalize_hit_from(const DScene& S, const InstT* table, V3 o, V3 dir,
       const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
       float u = B.mh.u, v = B.mh.v, w = 1.0f - u - v;
       uvw = v3(0, 0, 0);
-      if (I.has_uvw) {
+      if (I.has_uvw && wants_uvw(I)) {
         const float4 f3 = fr[3], f4 = fr[4];
         uvw = (v3(f0.w, f1.w, f2.w) * w) + (v3(f3.x, f3.y, f3.z) * u) + (v3(f3.w, f4.x, f4.y) * v);
       }

@@ -910,7 +910,9 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         V3 h = normalized(lightDir + sp.V);
         float cosphi = fmaxf(dot(sp.N, h), 0.0f);
         float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
-        contrib = w * (inten * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
+        // (0 * powf(..) is +0 for every finite power of a cosine in [0, 1]: a wave of purely diffuse points skips powf)
+        const float spec = nonzero(cKs) ? powf(cosphi, alpha) : 0.0f;
+        contrib = w * (inten * ((costheta * cKd) + (cKs * spec)));
         lit = nonzero(contrib);
         if (lit && soft) {
           float rl[4];

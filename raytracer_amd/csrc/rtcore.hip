@@ -883,6 +883,9 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       R.prim = inst[i].prim; R.node = inst[i].node; R.depth = inst[i].depth; R.xf_off = inst[i].xf_off;
       R.shade_base = inst[i].prim == RT_PRIM_MESH ? inst[i].shade_base : 0u; R.has_uvw = inst[i].has_uvw;
       R.mtl = mtls[inst[i].mtl];
+      const DMaterial& M = R.mtl;
+      R.uses_uvw = (M.diffuse.map >= 0 || M.specular.map >= 0 || M.emission.map >= 0 || M.reflection.map >= 0 || M.refraction.map >= 0 ||
+                    M.glossiness.map >= 0) ? 1u : 0u;
     }
     if ((rc = upload(ctx, ctx->scene_mem, sinst, &D.sinst))) return rc;
   }
