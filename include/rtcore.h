@@ -346,8 +346,11 @@ int rt_profile_get(rt_context* ctx, rt_profile* out);
 /* Developer knobs of one context (the reference's counterparts are compile-time constants, raytracer.h:17-23): "tlas_min"
  * (instances from which the instance BVH replaces the scene-graph table walk; applies at the next rt_scene_commit),
  * "gather_hints" (0: every photon lookup from scratch), "frame_gb" (stage-queue memory of one pass), "fan_scale" (scales the
- * measured queue sizing; tests force the overflow path with it), "timing".  Their initial values come from the environment
- * variables RT_TLAS_MIN / RT_GATHER_HINTS / RT_FRAME_GB / RT_TEST_FAN_SCALE / RT_TIMING, read once by rt_context_create. */
+ * measured queue sizing; tests force the overflow path with it), "timing", "soft_clear" (0: every soft-shadow group is traced;
+ * 1, the default: groups with a proven clear view of their light, or proven to lie in a sphere's full shadow, are finished
+ * without their rays — the same frame either way, rt_counters.rays_shadow_proven counts what was saved).  Their initial values
+ * come from the environment variables RT_TLAS_MIN / RT_GATHER_HINTS / RT_FRAME_GB / RT_TEST_FAN_SCALE / RT_TIMING /
+ * RT_SOFT_CLEAR, read once by rt_context_create. */
 int rt_set_option(rt_context* ctx, const char* name, double value);
 /* Number of device allocations (hipMalloc) made so far on behalf of this context: the entry points keep their device
  * buffers in the context and grow them only, so a steady-state caller sees this stand still (no counterpart in the
