@@ -414,6 +414,22 @@ def main():
                 for k in ("valu_issue_util", "active_lane_ratio", "occupancy_waves_per_simd", "l2_hit_rate"):
                     e[k] = m.get(k)
             per_kernel[name] = e
+        # BVH-node vs triangle-slot attribution of the mesh kernels.  The PMC counters see HBM traffic per
+        # kernel, not per buffer; what can be stated per buffer is its algorithmic bytes (32 B per box tested, 48 B per slot
+        # tested) and its resident size — the traffic measured for the whole kernel bounds what either array drew from HBM,
+        # and algorithmic / measured is the reuse the caches delivered.
+        n_dev_nodes = sum(max(int(scene.desc.meshes[i].n_bvh_nodes) - 1, 0) // 2 for i in range(scene.desc.n_meshes))
+        resident = {"bvh_nodes": 64 * n_dev_nodes if n_dev_nodes else None, "triangle_slots": 48 * scene.n_triangles()}
+        for name, nodes, tris, items in (("k_trace_mesh", cnt["closest_node_visits"], cnt["closest_tri_tests"], cnt["mesh_items"]),
+                                         ("k_shadow_mesh", sh_nodes, sh_tris, 0)):
+            e = per_kernel.get(name)
+            if e:
+                lps = e["launches_per_step"]
+                e["buffers"] = {"bvh_nodes": {"algorithmic_bytes_per_launch": 32.0 * nodes / lps, "resident_bytes": resident["bvh_nodes"]},
+                                "triangle_slots": {"algorithmic_bytes_per_launch": 48.0 * tris / lps, "resident_bytes": resident["triangle_slots"]},
+                                "work_items": {"algorithmic_bytes_per_launch": 48.0 * items / lps}}
+                if e["hbm_traffic_bytes_per_launch"]:
+                    e["buffers"]["cache_reuse"] = (32.0 * nodes + 48.0 * tris) / lps / e["hbm_traffic_bytes_per_launch"]
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])   # the kernel with the most time in the timed region
         d = per_kernel[dom]
         # The binding roof: the largest MEASURED utilisation when this build's counters are at hand (HBM traffic against

@@ -323,10 +323,16 @@ RT_DEV float wave_max(float v) {
   return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 }
 RT_DEV bool wave_any(bool v) { return __ballot(v) != 0ull; }
+RT_DEV uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 #else
 RT_DEV float wave_min(float v) { return v; }
 RT_DEV float wave_max(float v) { return v; }
 RT_DEV bool wave_any(bool v) { return v; }
+RT_DEV uint32_t wave_or(uint32_t v) { return v; }
 #endif
 
 // ---- segmented queues ------------------------------------------------------------------------------
@@ -1058,9 +1064,12 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 // Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
 // SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
 // `active`: this lane has a ray (the first-phase kernels call with every lane of the wave, see the wave-wide cull below).
-template <bool CNT, bool SPLIT>
+// MASKED: `inst_mask` names the instances (bit i: table entry i < 32; entries from 32 on always count) that can occlude this
+// lane's ray at all — what cone_clear could not exclude for the ray's soft-shadow group; the wave tests the union.
+template <bool CNT, bool SPLIT, bool MASKED = false>
 RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& cand_head, const CandSink& K, uint32_t* stk, uint32_t stride,
-                          Cnt<CNT>& cnt, bool active = true) {
+                          Cnt<CNT>& cnt, bool active = true, uint32_t inst_mask = 0xFFFFFFFFu) {
+  const uint32_t wmask = MASKED ? wave_or(active ? inst_mask : 0u) : 0xFFFFFFFFu;
   V3 winv = v3(0, 0, 0);
   if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
@@ -1101,6 +1110,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
           const DInstance& J = S.inst[li];
           keep = !(smin.x > J.wmax[0] || smax.x < J.wmin[0] || smin.y > J.wmax[1] || smax.y < J.wmin[1] || smin.z > J.wmax[2] ||
                    smax.z < J.wmin[2]);
+          if (MASKED && li < 32) keep = keep && ((wmask >> li) & 1u);
         }
         live = __ballot(keep);
       }
@@ -1114,6 +1124,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
     if (SPLIT && (smin.x > I->wmax[0] || smax.x < I->wmin[0] || smin.y > I->wmax[1] || smax.y < I->wmin[1] || smin.z > I->wmax[2] ||
                   smax.z < I->wmin[2]))
       continue;
+    if (MASKED && i < 32 && !((wmask >> i) & 1u)) continue;
 #endif
     int prim = I->prim;
     V3 p, d;
@@ -1198,13 +1209,15 @@ RT_DEV float rt_fast_sqrt(float x) { return sqrtf(x); }
 #define RT_CONE_TRACE 0
 #define RT_CONE_CLEAR 1
 #define RT_CONE_UMBRA 2
-RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
+// `may_occlude`: bit i = table entry i (< 32) could not be excluded for this group's rays (any_instances<.., MASKED>).
+RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_t& may_occlude) {
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   const V3 a = C - P;
   const float len = rt_fast_sqrt(dot(a, a));
   const bool sized = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
   bool clear = sized, umbra = false;
+  may_occlude = sized ? 0u : 0xFFFFFFFFu;
   const V3 ainv = v3(rt_fast_rcp(a.x), rt_fast_rcp(a.y), rt_fast_rcp(a.z));
   const float s_max = 1.0f + 1.01f * R * rt_fast_rcp(len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
   const float Rw = R * 1.002f + 1e-4f;
@@ -1216,9 +1229,9 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
     const bool touch = sized && !umbra && box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw, I->wmax[1] + Rw,
                                                    I->wmax[2] + Rw, tm) && !(tm > s_max);
     const int prim = I->prim;
-    if (!wave_any(touch && (clear || prim == 1))) continue;   // [wave-uniform]
+    if (!wave_any(touch)) continue;   // [wave-uniform]
     if (prim == 3) {
-      if (touch) clear = false;
+      if (touch) { clear = false; if (i < 32) may_occlude |= 1u << i; }
       continue;
     }
     // the segment in the instance's space (the same transforms, in the same order, as the rays' own: P lands on the
@@ -1276,7 +1289,7 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active) {
         if (covers || through) umbra = true;
       }
     }
-    if (touch && !free_of) clear = false;
+    if (touch && !free_of) { clear = false; if (i < 32) may_occlude |= 1u << i; }
   }
   return umbra ? RT_CONE_UMBRA : (clear ? RT_CONE_CLEAR : RT_CONE_TRACE);
 }

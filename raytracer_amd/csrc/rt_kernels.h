@@ -38,7 +38,7 @@ struct GroupQ {  // one record per (shade point, light) whose unshadowed contrib
   float4* g1;    // weight * unshadowed BRDF term rgb, path slot
   float4* g2;    // disc offsets rx, ry (lights.cpp:25-26), lit-sample counter, unused
   float4* g3;    // soft groups: disc tangent (lights.cpp:32), light size     -- the same for every sample of the group,
-  float4* g4;    // soft groups: disc bitangent, unused                          computed once by k_shade
+  float4* g4;    // soft groups: disc bitangent, instances that may occlude      computed once by k_shade
   uint32_t* counts;
   uint32_t segcap;
   uint32_t nseg;
@@ -930,7 +930,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
           V3 tangent, bitangent;
           orthonormals(toSP, tangent, bitangent);
           GS.g3[gi] = make_float4(tangent.x, tangent.y, tangent.z, L->size * P.light_size_scale);
-          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, 0.0f);
+          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, __uint_as_float(0xFFFFFFFFu));   // (.w: instances that may occlude, k_shadow_soft_clear)
         }
       } else {
         uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
@@ -1052,7 +1052,7 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
   const uint32_t* counts = list ? list_counts : G.counts;
   const unsigned long long nj_magic = ((1ull << 40) + nj - 1u) / nj;   // ceil(2^40 / nj): e / nj == (e * magic) >> 40 for e < 2^32
   RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
-    uint32_t g = RT_NONE, j = 0;
+    uint32_t g = RT_NONE, j = 0, inst_mask = 0xFFFFFFFFu;
     uint32_t head = RT_NONE;
     bool lit = false;
     V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
@@ -1065,13 +1065,15 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
       uint32_t e = seg_base_ + q;
       g = list ? list[e] : e;
       j = j0 + (e32 - q * nj);
-      soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], G.g4[g], j, Pp, d, dist);
+      const float4 g4 = G.g4[g];
+      inst_mask = __float_as_uint(g4.w);
+      soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], g4, j, Pp, d, dist);
       rays++;
     }
     const CandSink K = cand_sink(MQ, sw_.s % MQ.nseg, F.overflow);
     bool occ;
     if (TLAS) occ = seg_valid && any_instances_tlas<CNT, true>(S, Pp, d, dist, head, K, stk, stride, cnt);
-    else occ = any_instances<CNT, true>(S, Pp, d, dist, head, K, stk, stride, cnt, seg_valid);  // (every lane: wave-wide cull and appends)
+    else occ = any_instances<CNT, true, true>(S, Pp, d, dist, head, K, stk, stride, cnt, seg_valid, inst_mask);  // (every lane: wave-wide cull and appends)
     const bool need_mesh = seg_valid && !occ && head != RT_NONE;
     if (seg_valid && !occ && head == RT_NONE) lit = true;
     run_count_add(lit, g, seg_valid ? (uint32_t*)&G.g2[g].z : nullptr);
@@ -1187,14 +1189,18 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
       C = v3(L.position[0], L.position[1], L.position[2]);
       R = G.g3[g].w;
     }
-    const int view = cone_clear(S, Pp, C, R, seg_valid);
+    uint32_t may_occlude;
+    const int view = cone_clear(S, Pp, C, R, seg_valid, may_occlude);
     if (seg_valid && view == RT_CONE_CLEAR) {
       const float4 g1 = G.g1[g];
       add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * 1.0f);
     }
     if (CNT && seg_valid) proven += view == RT_CONE_CLEAR ? (uint32_t)P.shadow_min : (view == RT_CONE_UMBRA ? (uint32_t)(P.shadow_max > P.shadow_min ? P.shadow_max : P.shadow_min) : 0u);
     uint32_t li = seg_push(seg_valid && view == RT_CONE_TRACE, n1, sw_.s, G.segcap, F.overflow);
-    if (li != RT_NONE) list1[li] = g;
+    if (li != RT_NONE) {
+      list1[li] = g;
+      ((uint32_t*)&G.g4[g])[3] = may_occlude;   // the rays of this group are tested against these instances only (k_shadow_soft)
+    }
   RT_SEG_END
   if (CNT && proven) rt_atomic_add_u64(&F.counters->rays_shadow_proven, proven);
 }
