@@ -1086,7 +1086,10 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
   // tests every node for every ray (RayTracer.cpp:346-371); the result is the same.  (A per-lane skip does not pay: the
   // wave still runs the test whenever one lane needs it.)
   V3 smin = v3(-RT_BIG, -RT_BIG, -RT_BIG), smax = v3(RT_BIG, RT_BIG, RT_BIG);
-  if (SPLIT) {
+  // (with a mask that covers the whole table the mask is the cull: it is per group and exact about shapes, the box is
+  // per wave and about boxes)
+  const bool box_cull = SPLIT && !(MASKED && S.n_inst <= 32 && wmask != 0xFFFFFFFFu);   // [wave-uniform]
+  if (box_cull) {
     const float tseg = t_max < 1e30f ? t_max : 1e30f;
     const V3 e = o + dir * tseg;
     smin = v3(wave_min(active ? fminf(o.x, e.x) : RT_BIG), wave_min(active ? fminf(o.y, e.y) : RT_BIG), wave_min(active ? fminf(o.z, e.z) : RT_BIG));
