@@ -62,7 +62,8 @@
 #define RT_BLOCKS_PER_CU 8   // streaming kernels: measured 4 -> 8 blocks per CU: k_shade 5.8 -> 4.8 ms per bench step
 #endif
 #ifndef RT_CONE_MAX_INST
-#define RT_CONE_MAX_INST 256   // soft-shadow proofs (cone_clear) walk the instance table linearly
+#define RT_CONE_MAX_INST 64    // soft-shadow proofs (cone_clear) walk the instance table linearly: ~25 instructions per entry and group,
+                               // against the 16 rays through the instance BVH (~300 each) a proof may save
 #endif
 #ifndef RT_TLAS_MIN
 #define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
