@@ -1222,6 +1222,7 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_
   bool clear = sized, umbra = false;
   may_occlude = sized ? 0u : 0xFFFFFFFFu;
   const V3 ainv = v3(rt_fast_rcp(a.x), rt_fast_rcp(a.y), rt_fast_rcp(a.z));
+  const bool ainv_finite = fabsf(ainv.x) <= RT_BIG && fabsf(ainv.y) <= RT_BIG && fabsf(ainv.z) <= RT_BIG;
   const float s_max = 1.0f + 1.01f * R * rt_fast_rcp(len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
   const float Rw = R * 1.002f + 1e-4f;
   ParentRay pr;
@@ -1229,8 +1230,9 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
     float tm;
-    const bool touch = sized && !umbra && box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw, I->wmax[1] + Rw,
-                                                   I->wmax[2] + Rw, tm) && !(tm > s_max);
+    // (a segment parallel to an axis has an infinite reciprocal, and 0 x inf in a slab is NaN: no box is skipped on that)
+    const bool touch = sized && !umbra && (!ainv_finite || (box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw,
+                                                                     I->wmax[1] + Rw, I->wmax[2] + Rw, tm) && !(tm > s_max)));
     const int prim = I->prim;
     if (!wave_any(touch)) continue;   // [wave-uniform]
     if (prim == 3) {
