@@ -466,14 +466,16 @@ def check_device_bvh(r, scene, w, h, n_rays):
     return trees, depths
 
 
-def check_soft_shadow_clear_view(r, scene, w, h, spp=1, tol=2e-6, min_saved=0.2, strict=None, gate=None):
+def check_soft_shadow_clear_view(r, scene, w, h, spp=1, tol=2e-6, min_saved=0.2, strict=None, gate=None, light_scale=1.0, shadow=None):
     """Soft-shadow groups with a proven clear view of their whole light, or proven to lie in a sphere's full shadow, are
     finished without a ray (cone_clear): the frame must be the one that traces every group (same groups, same terms; only
     the order of the float atomics on a path's radiance differs), with the oracle as the third opinion, and the shortcut
     must actually save rays."""
     import oracle_ffi
     r.LoadScene(scene)
-    p = params(w, h, spp=spp, jitter=1, bounces=1, light_scale=1.0)
+    p = params(w, h, spp=spp, jitter=1, bounces=1, light_scale=light_scale)
+    if shadow is not None:   # (the reference's constants are 16 / 128, raytracer.h:17-23)
+        p.shadow_min, p.shadow_max = shadow
     out = {}
     for mode in (1, 0):
         r.set_option("soft_clear", mode)

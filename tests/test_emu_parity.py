@@ -94,6 +94,12 @@ def test_soft_shadow_clear_view_shortcut(emu):
     print("cornell_box: shadow rays", n1, "of", n0)
     common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("c3_cornell_textured.xml")), 48, 27, strict=1e-4)
     print("random scene graphs: shadow rays %d of %d" % common_checks.check_soft_shadow_clear_view_random(emu, range(4, 10), 64, 48, strict=1e-4))
+    # a light three times the size (wider cones), and sample counts other than 16 / 128 — among them min = max, where every
+    # group ends after the first phase
+    cb = Scene.load(scene_path("cornell_box.xml"))
+    common_checks.check_soft_shadow_clear_view(emu, cb, 64, 48, strict=1e-4, light_scale=3.0)
+    common_checks.check_soft_shadow_clear_view(emu, cb, 64, 48, strict=1e-4, shadow=(4, 40))
+    common_checks.check_soft_shadow_clear_view(emu, cb, 64, 48, strict=1e-4, shadow=(8, 8))
 
 
 def test_device_bvh_build(emu, tmp_path):

@@ -68,6 +68,10 @@ def test_soft_shadow_clear_view_shortcut(gpu_renderer):
         n1, n0 = cc.check_soft_shadow_clear_view(gpu_renderer, Scene.load(scene_path(name)), w, h, spp=2, tol=1e-5)
         print(name, "shadow rays", n1, "of", n0)
     print("random scene graphs: shadow rays %d of %d" % cc.check_soft_shadow_clear_view_random(gpu_renderer, range(0, 12), 160, 120, tol=1e-5))
+    cb = Scene.load(scene_path("cornell_box.xml"))   # a wider light, other sample counts (min = max: one phase only)
+    cc.check_soft_shadow_clear_view(gpu_renderer, cb, 320, 240, tol=1e-5, light_scale=3.0)
+    cc.check_soft_shadow_clear_view(gpu_renderer, cb, 320, 240, tol=1e-5, shadow=(4, 40))
+    cc.check_soft_shadow_clear_view(gpu_renderer, cb, 320, 240, tol=1e-5, shadow=(8, 8))
     stress = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
     cc.check_soft_shadow_clear_view(gpu_renderer, stress, 160, 90, tol=1e-5, min_saved=-1.0)
 
