@@ -76,6 +76,19 @@ def test_soft_shadow_clear_view_shortcut(gpu_renderer):
     cc.check_soft_shadow_clear_view(gpu_renderer, stress, 160, 90, tol=1e-5, min_saved=-1.0)
 
 
+def test_soft_shadow_proofs_full_size(gpu_renderer):
+    """BASELINE configs 3 and 4 at their full frame sizes with their own integrator settings (C3: 4K, Monte-Carlo indirect, three
+    bounces; C4's Cornell box at 1080p): the frame with the proofs equals the frame that traces every group — ids exactly,
+    radiance to 1e-5 — and traced + proven rays add up to the rays of the traced frame."""
+    n1, n0 = cc.check_soft_shadow_clear_view(gpu_renderer, Scene.load(scene_path("c3_cornell_textured.xml")), 3840, 2160, tol=1e-5,
+                                             with_oracle=False, bounces=3, mc=2)
+    print("C3 4K x 1: shadow rays", n1, "of", n0)
+    assert n1 < 0.25 * n0
+    n1, n0 = cc.check_soft_shadow_clear_view(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), 1920, 1080, spp=2, tol=1e-5,
+                                             with_oracle=False, bounces=3)
+    print("Cornell box 1080p x 2: shadow rays", n1, "of", n0)
+
+
 def test_device_bvh_build(gpu_renderer):
     """n2: meshes without a tree get a linear BVH on the device at rt_scene_commit (rt_bvh_build.h): a valid BVH of the mesh,
     and with the oracle walking the SAME tree (rt_scene_mesh_bvh) node + face ids are bit-exact and the batched closest /
