@@ -25,7 +25,7 @@ typedef struct rth_scene rth_scene;
 /* Loads a scene file in the reference's XML dialect.  Texture and OBJ names are resolved
  * relative to `asset_dir` first (NULL = directory of the file), then to the CWD as the
  * reference does (texture.cpp:86,95).  Mesh names of the form
- *   gen:<kind>?seed=<n>&tris=<n>      (kind: teapot_like | icosphere | terrain | blob)
+ *   gen:<kind>?seed=<n>&tris=<n>[&size=<f>]   (kind: teapot_like | icosphere | terrain | blob | voxels)
  * are produced by the seeded procedural generator instead of being read from disk
  * (the reference's .obj assets are git-ignored and absent).
  * Returns NULL on error; the message is available from rth_last_error(). */
@@ -41,14 +41,21 @@ const char* rth_scene_node_name(const rth_scene* s, int node);
 /* Number of warnings the loader printed (unknown tags, missing assets...). */
 int rth_scene_warnings(const rth_scene* s);
 
-/* Process-wide switch for the scenes loaded or generated afterwards: 1 (default) = every mesh gets its BVH here
- * (binned SAH, as TriObj::Load builds one on load, objects.h:65); 0 = meshes are handed over without a tree
- * (rt_mesh::bvh == NULL) and rt_scene_commit builds a linear BVH on the device. */
+/* Load flags of the *_ex entry points. */
+#define RTH_LOAD_NO_BVH 1u /* meshes are handed over without a tree (rt_mesh::bvh == NULL): rt_scene_commit builds a
+                              linear BVH on the device.  Default: every mesh gets its BVH here (binned SAH, as
+                              TriObj::Load builds one on load, objects.h:65). */
+rth_scene* rth_scene_load_file_ex(const char* path, const char* asset_dir, uint32_t flags);
+rth_scene* rth_scene_load_string_ex(const char* xml_text, const char* asset_dir, uint32_t flags);
+
+/* The same choice as a switch of the CALLING THREAD for the scenes it loads or generates afterwards through the entry
+ * points without flags (1 = build here, the default; 0 = RTH_LOAD_NO_BVH).  Other threads are not affected. */
 void rth_set_host_bvh(int on);
 
 /* Synthetic stress scene (BASELINE config 5): n_instances icospheres of 20*4^subdiv triangles
  * baked into ONE world-space mesh plus a displaced ground grid, two sphere lights. */
 rth_scene* rth_scene_generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height);
+rth_scene* rth_scene_generate_stress_ex(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height, uint32_t flags);
 
 /* PNG output (8-bit RGB or grey).  0 on success. */
 int rth_write_png(const char* path, const uint8_t* pixels, int width, int height, int channels);

@@ -53,32 +53,24 @@ class Scene:
         self.desc = self.desc_ptr.contents
 
     # host_bvh=False: the meshes come without a tree and Renderer.LoadScene (rt_scene_commit) builds it on the device
+    # (a per-call flag of the loader: nothing process-wide is switched)
     @classmethod
     def load(cls, path, asset_dir=None, host_bvh=True):
         host = _ffi.load_host()
-        host.rth_set_host_bvh(1 if host_bvh else 0)
-        try:
-            return cls(host.rth_scene_load_file(os.fsencode(path), os.fsencode(asset_dir) if asset_dir else None))
-        finally:
-            host.rth_set_host_bvh(1)
+        flags = 0 if host_bvh else _ffi.RTH_LOAD_NO_BVH
+        return cls(host.rth_scene_load_file_ex(os.fsencode(path), os.fsencode(asset_dir) if asset_dir else None, flags))
 
     @classmethod
     def from_string(cls, xml, asset_dir=None, host_bvh=True):
         host = _ffi.load_host()
-        host.rth_set_host_bvh(1 if host_bvh else 0)
-        try:
-            return cls(host.rth_scene_load_string(xml.encode(), os.fsencode(asset_dir) if asset_dir else None))
-        finally:
-            host.rth_set_host_bvh(1)
+        flags = 0 if host_bvh else _ffi.RTH_LOAD_NO_BVH
+        return cls(host.rth_scene_load_string_ex(xml.encode(), os.fsencode(asset_dir) if asset_dir else None, flags))
 
     @classmethod
     def stress(cls, seed=7, n_instances=2048, subdiv=4, ground_res=1024, width=3840, height=2160, host_bvh=True):
         host = _ffi.load_host()
-        host.rth_set_host_bvh(1 if host_bvh else 0)
-        try:
-            return cls(host.rth_scene_generate_stress(seed, n_instances, subdiv, ground_res, width, height))
-        finally:
-            host.rth_set_host_bvh(1)
+        flags = 0 if host_bvh else _ffi.RTH_LOAD_NO_BVH
+        return cls(host.rth_scene_generate_stress_ex(seed, n_instances, subdiv, ground_res, width, height, flags))
 
     def with_bvh(self, trees):
         """A view of this scene whose meshes carry other trees: `trees[mesh_id]` = (nodes, elements) as

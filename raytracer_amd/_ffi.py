@@ -188,6 +188,12 @@ def load_host():
     lib.rth_free.argtypes = [C.c_void_p]
     lib.rth_set_host_bvh.argtypes = [C.c_int]
     lib.rth_set_host_bvh.restype = None
+    lib.rth_scene_load_file_ex.restype = C.c_void_p
+    lib.rth_scene_load_file_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+    lib.rth_scene_load_string_ex.restype = C.c_void_p
+    lib.rth_scene_load_string_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+    lib.rth_scene_generate_stress_ex.restype = C.c_void_p
+    lib.rth_scene_generate_stress_ex.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
     _host = lib
     return lib
 
@@ -203,8 +209,9 @@ CORE_SYMBOLS = [
 HOST_SYMBOLS = [
     "rth_scene_load_file", "rth_scene_load_string", "rth_scene_free", "rth_last_error", "rth_scene_desc",
     "rth_scene_node_name", "rth_scene_warnings", "rth_scene_generate_stress", "rth_write_png", "rth_read_image_rgb",
-    "rth_free", "rth_set_host_bvh",
+    "rth_free", "rth_set_host_bvh", "rth_scene_load_file_ex", "rth_scene_load_string_ex", "rth_scene_generate_stress_ex",
 ]
+RTH_LOAD_NO_BVH = 1
 
 
 def load_core():

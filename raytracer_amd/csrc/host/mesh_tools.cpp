@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -212,10 +213,16 @@ struct Builder {
     if (n >= 65536 && tasks_left.fetch_sub(1) > 0) {
       // the right half on a task of its own (disjoint range of idx, own output arrays), spliced in behind the left half
       Sub right;
-      std::thread worker([&] { build(right, mid, e, depth + 1); });
-      uint32_t l = build(out, b, mid, depth + 1);
+      std::exception_ptr worker_error, own_error;   // an exception (bad_alloc on a huge mesh) fails the load, not the process
+      std::thread worker([&] {
+        try { build(right, mid, e, depth + 1); } catch (...) { worker_error = std::current_exception(); }
+      });
+      uint32_t l = 0;
+      try { l = build(out, b, mid, depth + 1); } catch (...) { own_error = std::current_exception(); }
       worker.join();
       tasks_left.fetch_add(1);
+      if (own_error) std::rethrow_exception(own_error);
+      if (worker_error) std::rethrow_exception(worker_error);
       uint32_t r = (uint32_t)nodes.size();
       splice(out, right);
       nodes[me].a = l;
@@ -233,8 +240,10 @@ struct Builder {
 
 }  // namespace
 
-static std::atomic<int> g_host_bvh{1};
+// per thread: two threads loading scenes with different choices do not see each other's
+static thread_local int g_host_bvh = 1;
 void set_host_bvh(int on) { g_host_bvh = on ? 1 : 0; }
+int get_host_bvh() { return g_host_bvh; }
 
 void HostMesh::build_bvh(int max_leaf, int max_depth) {
   bvh.clear();
@@ -496,6 +505,30 @@ void make_terrain(HostMesh& m, uint32_t seed, int res, float size, float height)
   finish(m);
 }
 
+// n unit cubes at seeded lattice points of a 48 x 40 x 18 block region, every face a textured quad with its own four
+// vertices (flat normals, uv 0..1 per face): the shape of one per-material piece of a block world (the reference's
+// scenes/minecraft_world/*.obj, absent from its checkout, are such pieces).
+void make_voxels(HostMesh& m, uint32_t seed, int n) {
+  static const int F[6][4][3] = {{{0, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 0}}, {{0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}},
+                                 {{0, 0, 0}, {1, 0, 0}, {1, 0, 1}, {0, 0, 1}}, {{0, 1, 0}, {0, 1, 1}, {1, 1, 1}, {1, 1, 0}},
+                                 {{0, 0, 0}, {0, 0, 1}, {0, 1, 1}, {0, 1, 0}}, {{1, 0, 0}, {1, 1, 0}, {1, 1, 1}, {1, 0, 1}}};
+  static const float UV[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int c = 0; c < n; c++) {
+    const float ox = std::floor(hash01((uint32_t)c, 1, 7, seed) * 48.0f) - 24.0f;
+    const float oy = std::floor(hash01((uint32_t)c, 2, 7, seed) * 40.0f) - 30.0f;
+    const float oz = std::floor(hash01((uint32_t)c, 3, 7, seed) * 18.0f) + 14.0f;
+    for (int f = 0; f < 6; f++) {
+      const uint32_t base = (uint32_t)(m.pos.size() / 3);
+      for (int k = 0; k < 4; k++) {
+        m.pos.insert(m.pos.end(), {ox + F[f][k][0], oy + F[f][k][1], oz + F[f][k][2]});
+        m.uvw.insert(m.uvw.end(), {UV[k][0], UV[k][1], 0.0f});
+      }
+      m.fpos.insert(m.fpos.end(), {base, base + 1, base + 2, base, base + 2, base + 3});
+    }
+  }
+  finish(m);
+}
+
 }  // namespace
 
 void make_icosphere(HostMesh& m, int subdiv) {
@@ -564,6 +597,7 @@ bool generate_mesh(const std::string& spec, HostMesh& mesh, std::string& err) {
   if (q != std::string::npos) { kind = spec.substr(0, q); query = spec.substr(q + 1); }
   uint32_t seed = 1;
   long tris = 4096;
+  float size = 1.0f;   // uniform scale of the generated positions (stand-ins for meshes of another native size)
   std::stringstream ss(query);
   std::string kv;
   while (std::getline(ss, kv, '&')) {
@@ -572,6 +606,7 @@ bool generate_mesh(const std::string& spec, HostMesh& mesh, std::string& err) {
     std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
     if (k == "seed") seed = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
     else if (k == "tris") tris = std::strtol(v.c_str(), nullptr, 10);
+    else if (k == "size") size = std::strtof(v.c_str(), nullptr);
   }
   if (tris < 8) tris = 8;
   mesh = HostMesh();
@@ -595,9 +630,16 @@ bool generate_mesh(const std::string& spec, HostMesh& mesh, std::string& err) {
   } else if (kind == "terrain") {
     int res = std::max(2, (int)std::sqrt((double)tris / 2.0));
     make_terrain(mesh, seed, res, 2.0f, 0.35f);
+  } else if (kind == "voxels") {
+    make_voxels(mesh, seed, std::max(1, (int)(tris / 12)));
   } else {
     err = "unknown procedural mesh kind '" + kind + "'";
     return false;
+  }
+  if (size != 1.0f && size > 0.0f) {
+    for (float& x : mesh.pos) x *= size;
+    mesh.compute_bounds();
+    mesh.build_bvh(4);
   }
   return true;
 }

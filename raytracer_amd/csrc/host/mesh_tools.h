@@ -35,14 +35,16 @@ struct HostMesh {
   void fill(rt_mesh& out) const;
 };
 
-// 0: meshes are handed over without a tree (rt_mesh::bvh == NULL) and the renderer core builds it on the device
+// 0: meshes are handed over without a tree (rt_mesh::bvh == NULL) and the renderer core builds it on the device.
+// The choice is per calling thread; the loaders' *_ex entry points set it for one call and restore it.
 void set_host_bvh(int on);
+int get_host_bvh();
 
 // Wavefront OBJ subset: v / vt / vn / f (polygons fan-triangulated, negative indices), mtllib/usemtl.
 bool load_obj(const std::string& path, HostMesh& mesh, std::string& err);
 
 // Seeded procedural meshes standing in for the reference's absent .obj assets.
-// spec = "<kind>?seed=<n>&tris=<n>", kind in {teapot_like, icosphere, terrain, blob}.
+// spec = "<kind>?seed=<n>&tris=<n>", kind in {teapot_like, icosphere, terrain, blob, voxels}; optional &size=<f> scales the positions.
 bool generate_mesh(const std::string& spec, HostMesh& mesh, std::string& err);
 
 void make_icosphere(HostMesh& m, int subdiv);

@@ -464,11 +464,25 @@ rth_scene* load_text(const std::string& text, const char* asset_dir) {
 
 }  // namespace
 
+static rth_scene* generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height);
+namespace {
+struct BvhChoice {   // one call's choice of who builds the mesh BVHs; restores the thread's previous one
+  int prev;
+  explicit BvhChoice(uint32_t flags) : prev(get_host_bvh()) { set_host_bvh((flags & RTH_LOAD_NO_BVH) ? 0 : 1); }
+  ~BvhChoice() { set_host_bvh(prev); }
+};
+template <class F>
+rth_scene* guarded(F f) {   // nothing is thrown through the C boundary (bad_alloc in a BVH build of a huge mesh)
+  try { return f(); } catch (const std::exception& e) { g_err = std::string("scene load failed: ") + e.what(); } catch (...) { g_err = "scene load failed"; }
+  return nullptr;
+}
+}  // namespace
+
 extern "C" {
 
 rth_scene* rth_scene_load_string(const char* xml_text, const char* asset_dir) {
   if (!xml_text) { g_err = "null xml text"; return nullptr; }
-  return load_text(xml_text, asset_dir);
+  return guarded([&] { return load_text(xml_text, asset_dir); });
 }
 
 rth_scene* rth_scene_load_file(const char* path, const char* asset_dir) {
@@ -484,7 +498,20 @@ rth_scene* rth_scene_load_file(const char* path, const char* asset_dir) {
     size_t sl = p.find_last_of("/\\");
     dir = sl == std::string::npos ? "." : p.substr(0, sl);
   }
-  return load_text(ss.str(), dir.c_str());
+  return guarded([&] { return load_text(ss.str(), dir.c_str()); });
+}
+
+rth_scene* rth_scene_load_file_ex(const char* path, const char* asset_dir, uint32_t flags) {
+  BvhChoice c(flags);
+  return rth_scene_load_file(path, asset_dir);
+}
+rth_scene* rth_scene_load_string_ex(const char* xml_text, const char* asset_dir, uint32_t flags) {
+  BvhChoice c(flags);
+  return rth_scene_load_string(xml_text, asset_dir);
+}
+rth_scene* rth_scene_generate_stress_ex(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height, uint32_t flags) {
+  BvhChoice c(flags);
+  return rth_scene_generate_stress(seed, n_instances, subdiv, ground_res, width, height);
 }
 
 void rth_scene_free(rth_scene* s) { delete s; }
@@ -499,6 +526,11 @@ void rth_set_host_bvh(int on) { set_host_bvh(on); }
 
 // BASELINE config 5 stand-in: instanced icospheres baked into one world-space mesh + displaced ground.
 rth_scene* rth_scene_generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height) {
+  return guarded([&] { return generate_stress(seed, n_instances, subdiv, ground_res, width, height); });
+}
+}  // extern "C"
+
+static rth_scene* generate_stress(uint32_t seed, int n_instances, int subdiv, int ground_res, int width, int height) {
   auto s = std::make_unique<rth_scene>();
   init_scene(*s);
   HostMesh ico;
@@ -562,5 +594,3 @@ rth_scene* rth_scene_generate_stress(uint32_t seed, int n_instances, int subdiv,
   c.fov = 40; c.width = width; c.height = height;
   return finish(std::move(s));
 }
-
-}  // extern "C"

@@ -52,7 +52,38 @@ def clouds(n=1024, seed=5):
     return (np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)
 
 
+def block_textures(seed=11):
+    """Six 160x160 block-face textures (16x16 pixel art, 10x nearest upscale) in the PNG kinds the reference's
+    scenes/minecraft_world/tex/*.png use: 2 / 4 / 8-bit palettes, RGBA, grey and RGB.  Written with PIL."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    out = os.path.join(ROOT, "scenes", "blocks")
+    os.makedirs(out, exist_ok=True)
+    base = [(0.35, 0.6, 0.25), (0.5, 0.38, 0.25), (0.55, 0.55, 0.58), (0.8, 0.75, 0.5), (0.25, 0.4, 0.75), (0.7, 0.3, 0.3)]
+    kinds = [("P", 4), ("P", 16), ("P", 256), ("RGBA", 0), ("L", 0), ("RGB", 0)]
+    for i, ((mode, colours), tone) in enumerate(zip(kinds, base)):
+        cell = rng.random((16, 16, 1)).astype(np.float32)
+        img = np.clip(np.array(tone, np.float32) * (0.6 + 0.7 * cell) + 0.08 * rng.random((16, 16, 3)), 0, 1)
+        img[0, :] *= 0.7
+        img[:, 0] *= 0.7      # a darker seam along two edges of every block face
+        rgb = (np.kron(img, np.ones((10, 10, 1), np.float32)) * 255 + 0.5).astype(np.uint8)
+        im = Image.fromarray(rgb)
+        if mode == "P":
+            im = im.quantize(colours)
+        elif mode == "RGBA":
+            im = im.convert("RGBA")
+            a = np.asarray(im).copy()
+            a[::20, ::20, 3] = 0      # (alpha is dropped by the loader: lodepng LCT_RGB, texture.cpp:86)
+            im = Image.fromarray(a)
+        elif mode == "L":
+            im = im.convert("L")
+        path = os.path.join(out, "block%d.png" % i)
+        im.save(path, bits=2 if colours == 4 else (4 if colours == 16 else 8)) if mode == "P" else im.save(path)
+        print(path, mode, colours, os.path.getsize(path))
+
+
 def main():
+    block_textures()
     from raytracer_amd import _ffi
     host = _ffi.load_host()
     for name, img in (("tex_bricks.png", bricks()), ("tex_clouds.png", clouds())):

@@ -525,7 +525,7 @@ def check_soft_shadow_clear_view_random(r, seeds, w, h, strict=None, tol=2e-6):
 
 def check_reference_scene_fixtures(r, w, h, strict=None):
     """north_star: "every bundled scene renders within tolerance of the CPU reference".  tests/golden/scenes/ref_*.xml carry
-    the scene data of eight bundled reference scenes (nested transforms, direct + ambient + soft point lights, reflection /
+    the scene data of sixteen bundled reference scenes (nested transforms, direct + ambient + soft point lights, reflection /
     refraction / absorption, nested checkerboards, image textures on objects, background and environment, depth of field,
     nodes without material or lights, 49 glass spheres) to the GPU box; the reference's own files are read in place by
     test_emu_parity where the checkout exists."""
@@ -535,7 +535,7 @@ def check_reference_scene_fixtures(r, w, h, strict=None):
     from conftest import GOLDEN, ROOT
     from raytracer_amd import Scene
     files = sorted(glob.glob(os.path.join(GOLDEN, "scenes", "ref_*.xml")))
-    assert len(files) >= 8
+    assert len(files) >= 16
     for f in files:
         scene = Scene.load(f, asset_dir=ROOT)
         assert scene.warnings == 0, f
@@ -554,3 +554,51 @@ def check_reference_scene_fixtures(r, w, h, strict=None):
             # (few shadow samples per group, 4..8: one shadow ray that an ulp flips at a silhouette changes a whole group's
             # early-out, so single pixels differ visibly — measured 4 of 14 400 pixels, 70 dB, on ref_soft_shadow_scene)
             assert_stochastic_close(g, c, os.path.basename(f), frac=0.999, psnr=60.0, mean=1e-5)
+
+
+MULTIMTL = """<xml><scene>
+  <object type="plane" name="floor" material="grey"> <scale value="30"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_illum2.obj"> <scale value="1.6"/> <translate x="-9" y="2" z="0"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_illum3.obj"> <scale value="1.6"/> <rotate angle="40" z="1"/> <translate x="-3" y="4" z="0"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_illum6.obj"> <scale value="1.6"/> <translate x="3" y="2" z="0"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_mapks.obj"> <scale value="1.6"/> <rotate angle="-30" z="1"/> <translate x="9" y="4" z="0"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_illum3.obj"> <scale value="0.8"/> <translate x="-1" y="-5" z="0"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_illum6.obj" material="grey"> <scale value="0.8"/> <translate x="4" y="-5" z="0"/> </object>
+  <material type="blinn" name="grey"> <diffuse value="0.6"/> <specular value="0.1"/> </material>
+  <material type="blinn" name="tests/golden/meshes/mm_mapks.obj"> <diffuse r="0.9" g="0.1" b="0.9"/> </material>
+  <light type="point"> <intensity value="300"/> <position x="-4" y="-12" z="16"/> <size value="1"/> <attenuation value="1"/> </light>
+  <light type="direct"> <intensity value="0.3"/> <direction x="1" y="2" z="-2"/> </light>
+  <background r="0.1" g="0.15" b="0.3"/> <environment r="0.3" g="0.4" b="0.6"/>
+</scene>
+<camera gamma="sRGB"> <position x="0" y="-26" z="9"/> <target x="0" y="1" z="2"/> <up x="0" y="0" z="1"/> <fov value="40"/>
+  <width value="160"/> <height value="90"/> </camera></xml>"""
+
+
+def load_multimtl_scene():
+    """Four of this repository's own OBJ + MTL pairs (tests/golden/meshes, usemtl groups, illum 2 / 3 / 6, map_Kd, map_Ks, Ni,
+    Tf) on nodes WITHOUT material=: LoadNode -> SetNodeMaterials -> CreateMultiMtl (xmlload.cpp:159, 294-343)."""
+    from conftest import ROOT
+    from raytracer_amd import Scene
+    return Scene.from_string(MULTIMTL, asset_dir=ROOT)
+
+
+def check_multimtl_scene(r, w, h, strict=None):
+    """The frame of the MultiMtl scene against the oracle: ids bit-exact, colour 1e-4 at the pixel centre, the stochastic
+    frame (reflection and refraction from illum 3 / 6, image textures from map_Kd / map_Ks, soft shadows) within the gate."""
+    import oracle_ffi
+    scene = load_multimtl_scene()
+    assert scene.warnings == 0
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p = params(w, h, spp=1, jitter=0, bounces=0)
+    g, c = r.Render(p), orc.render(p)
+    assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face)
+    assert len(np.unique(c.hit_node[c.hit_face >= 0])) == 6, "not every mesh node is in view"
+    assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4
+    p = params(w, h, spp=2, jitter=1, bounces=3)
+    g, (c, cnt) = r.Render(p), orc.render(p, want_counters=True)
+    assert cnt["tex_evals"] > 0 and cnt["rays_secondary"] > 0.05 * cnt["rays_primary"]
+    if strict is not None:
+        assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict
+        return None
+    return assert_stochastic_close(g, c, "MultiMtl scene", frac=0.999, psnr=60.0, mean=1e-5)

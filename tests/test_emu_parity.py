@@ -304,5 +304,9 @@ def test_every_bundled_reference_scene_renders_like_the_oracle(emu):
         assert psnr8(g.img, c.img) >= 60.0, f"{f}: PSNR {psnr8(g.img, c.img):.1f}"
 
 
+def test_multimtl_scene(emu):
+    common_checks.check_multimtl_scene(emu, 96, 54, strict=1e-4)
+
+
 def test_reference_scene_fixtures(emu):
     common_checks.check_reference_scene_fixtures(emu, 64, 36, strict=1e-4)

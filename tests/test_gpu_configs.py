@@ -178,9 +178,16 @@ def test_steady_state_calls_do_not_allocate(gpu_renderer):
 
 
 def test_reference_scene_fixtures(gpu_renderer):
-    """Eight bundled reference scenes (scene data fixtures) on the GPU against the oracle: ids bit-exact, colour 1e-4,
+    """Sixteen bundled reference scenes (scene data fixtures; scene3_2 = scene3 and cornellBox = cornell_box.xml make
+    eighteen) on the GPU against the oracle: ids bit-exact, colour 1e-4,
     stochastic frames within the gate of assert_stochastic_close."""
     cc.check_reference_scene_fixtures(gpu_renderer, 320, 180)
+
+
+def test_multimtl_scene(gpu_renderer):
+    """n1: OBJ + MTL pairs on nodes without material= (CreateMultiMtl, xmlload.cpp:319-343; sub-material 0) on the
+    GPU against the oracle."""
+    print("multimtl:", cc.check_multimtl_scene(gpu_renderer, 480, 270))
 
 
 def test_reduce_accumulators_over_rccl_single_rank(gpu_renderer):

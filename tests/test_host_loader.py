@@ -189,6 +189,55 @@ def test_obj_reader(tmp_path):
     _check_bvh(m)
 
 
+def test_multimtl_from_obj_material_library():
+    """An <object type="obj"> without material= whose OBJ names a material library gets a MultiMtl built from it
+    (LoadNode xmlload.cpp:159, SetNodeMaterials :294-315, CreateMultiMtl :319-343): Kd / Ks / Ns / Ni, map_Kd as the diffuse
+    texture, illum 3..7 => reflection = Ks, illum >= 6 => refraction = 1 - Tf, map_Ks replacing the DIFFUSE texture (sic,
+    :331) and becoming the reflection texture.  The triangle test never sets mtlID, so sub-material 0 — the
+    library's FIRST newmtl, not the group a face belongs to — is what shades; the flattened scene binds it directly."""
+    from common import load_multimtl_scene
+    s = load_multimtl_scene()
+    d = s.desc
+    assert s.warnings == 0 and d.n_meshes == 4 and d.n_nodes == 8
+    names = [s.node_name(i) for i in range(d.n_nodes)]
+    mat = lambda i: d.materials[d.nodes[i].material_id]
+    # every mesh is the lathe body (24 x 12 quads) + the canopy quad, fan-triangulated, with its own uvs
+    for i in range(4):
+        assert d.meshes[i].n_faces == 2 * 24 * 12 + 2 and d.meshes[i].n_uvw == 25 * 13 + 4 and d.meshes[i].uvw_idx
+    m = mat(names.index("tests/golden/meshes/mm_illum2.obj"))      # illum 2: no reflection, no refraction, map_Kd
+    assert m.kind == 1 and np.allclose(m.diffuse.value[:], [0.8, 0.6, 0.4]) and np.allclose(m.specular.value[:], [0.3] * 3)
+    assert m.glossiness.value == 40.0 and abs(m.ior - 1.3) < 1e-6
+    assert np.allclose(m.reflection.value[:], 0) and np.allclose(m.refraction.value[:], 0)
+    tm = d.texmaps[m.diffuse.map]
+    assert tm.kind == 2 and d.images[tm.image].width == 1024 and np.allclose(np.array(tm.itm.m[:])[[0, 4, 8]], 1)
+    first3 = names.index("tests/golden/meshes/mm_illum3.obj")
+    m = mat(first3)                                                  # illum 3: reflection = Ks
+    assert np.allclose(m.diffuse.value[:], [0.3, 0.5, 0.7]) and np.allclose(m.reflection.value[:], [0.5, 0.4, 0.3])
+    assert np.allclose(m.refraction.value[:], 0) and m.glossiness.value == 120.0 and abs(m.ior - 1.1) < 1e-6 and m.diffuse.map == -1
+    m = mat(names.index("tests/golden/meshes/mm_illum6.obj"))      # illum 6: reflection = Ks, refraction = 1 - Tf
+    assert np.allclose(m.reflection.value[:], [0.6] * 3) and np.allclose(m.refraction.value[:], [0.85, 0.9, 0.95])
+    assert abs(m.ior - 1.45) < 1e-6 and m.glossiness.value == 80.0
+    # a material already named like the node wins over the library (materials.Find(node->GetName()), :300)
+    m = mat(names.index("tests/golden/meshes/mm_mapks.obj"))
+    assert np.allclose(m.diffuse.value[:], [0.9, 0.1, 0.9]) and m.diffuse.map == -1
+    # the second node of the same file finds the material the first one created; material= beats the library
+    second3 = len(names) - 1 - names[::-1].index("tests/golden/meshes/mm_illum3.obj")
+    assert second3 != first3 and d.nodes[second3].material_id == d.nodes[first3].material_id
+    assert d.nodes[second3].mesh_id == d.nodes[first3].mesh_id          # objList.Find(name), :146
+    last6 = len(names) - 1 - names[::-1].index("tests/golden/meshes/mm_illum6.obj")
+    assert d.materials[d.nodes[last6].material_id].diffuse.value[0] == np.float32(0.6)
+    # the map_Ks quirk, on a scene where no material of that name pre-exists
+    from conftest import ROOT
+    q = Scene.from_string("""<xml><scene><object type="obj" name="tests/golden/meshes/mm_mapks.obj"/></scene><camera/></xml>""", asset_dir=ROOT)
+    m = q.desc.materials[q.desc.nodes[1].material_id]
+    dm, rm = q.desc.texmaps[m.diffuse.map], q.desc.texmaps[m.reflection.map]
+    assert q.desc.images[dm.image].width == 160 and q.desc.images[rm.image].width == 160     # map_Ks (block2.png), not map_Kd
+    assert np.allclose(m.reflection.value[:], [0.4] * 3) and np.allclose(m.refraction.value[:], 0)  # illum 4
+    # an OBJ without a library on a node without material=: no material at all (null material, SURVEY Q16)
+    q = Scene.from_string("""<xml><scene><object type="obj" name="gen:icosphere?seed=1&amp;tris=80"/></scene><camera/></xml>""")
+    assert q.desc.nodes[1].material_id == -1 and q.desc.n_materials == 0
+
+
 def test_stress_scene_generator():
     s = Scene.stress(seed=7, n_instances=16, subdiv=2, ground_res=16, width=64, height=36)
     m = s.desc.meshes[0]
