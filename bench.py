@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run (c2, one GPU): skip the short runs of the other configurations")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--device-bvh", action="store_true", help="mesh BVHs built at rt_scene_commit on the device instead of by the host loader")
     args = ap.parse_args()
@@ -274,6 +275,57 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     stat_dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
+    out = run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief=False)
+    if rank == 0:
+        if world == 1 and args.config == "c2" and not args.no_other_configs:
+            # every other BASELINE configuration (and the scene-graph stress case) in the same driver-run line: short runs
+            # (1 warm-up + 3 steps each), compact rows; their long CPU rows stay in profiles/ and BASELINE.md
+            out["config"]["other_configs"] = {}
+            for name in ("c1", "c3", "c4", "c5", "spheres"):
+                short = argparse.Namespace(**vars(args))
+                short.steps, short.warmup = 3, 1
+                t0 = time.perf_counter()
+                row = run_config(CONFIGS[name], short, rank, local_rank, world, stat_dev, dist, brief=True)
+                row["wall_s"] = round(time.perf_counter() - t0, 2)
+                out["config"]["other_configs"][name] = row
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def psnr_vs_oracle(cfg, scene, renderer, stride):
+    """GPU against the CPU oracle on every `stride`-th 32x32 tile, one sample per pixel of the configuration's own integrator
+    settings at the same Philox seed: PSNR of the 8-bit images and mean radiance difference (bounded: a second or two of CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_ffi
+    if not HOST_BVH:
+        scene = scene.with_bvh({i: renderer.GetMeshBVH(i) for i in range(scene.desc.n_meshes)})
+    orc = oracle_ffi.OracleScene(scene)
+    p = cfg.params(0)
+    p.tile_begin, p.tile_stride, p.tile_count = 0, stride, 0
+    p.sample_count = 1
+    if p.photons:
+        renderer.BuildPhotonMaps(p)
+        orc.photons_set_tree(0, renderer.GetPhotonTree(0))
+        orc.photons_set_tree(1, renderer.GetPhotonTree(1))
+    t0 = time.perf_counter()
+    c = orc.render(p, min(16, len(os.sched_getaffinity(0))))
+    cpu_s = time.perf_counter() - t0
+    g = renderer.Render(p)
+    covered = c.sample_count > 0
+    d = g.img[covered].astype(np.float64) - c.img[covered].astype(np.float64)
+    mse = float((d * d).mean())
+    return {"psnr_db": 99.0 if mse == 0 else 10.0 * float(np.log10(255.0 * 255.0 / mse)),
+            "mean_abs_radiance_diff": float(np.abs(g.radiance[covered][:, :3] - c.radiance[covered][:, :3]).mean()),
+            "pixels": int(covered.sum()), "tile_stride": stride, "spp": 1, "cpu_s": round(cpu_s, 2)}
+
+
+def run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief):
+    """Loads, commits and times one configuration.  brief: a compact row for the main line's other_configs."""
+    import torch
+    WIDTH, HEIGHT, SPP_PER_STEP = cfg.width, cfg.height, cfg.spp_per_step
     from raytracer_amd import Renderer, Scene, distributed
     t0 = time.perf_counter()
     scene = cfg.scene()       # host: XML / generator, meshes, BVH build
@@ -458,6 +510,8 @@ def main():
                        "rays_proven_per_step_per_gpu": cnt["rays_shadow_proven"],
                        "reference_equivalent_mrays_s": (rays_per_step + cnt["rays_shadow_proven"]) * world * args.steps / dt / 1e6,
                        "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",
+                       # what the exchange actually ran over (N > 1): the process group's backend and the ranks it saw
+                       "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": d["hbm_traffic_bytes_per_launch"],
@@ -473,12 +527,25 @@ def main():
                                  "profiles/ carries this kernel-source hash); per_kernel lists, for every hot kernel, the algorithmic and the "
                                  "measured HBM fraction, the algorithmic VALU fraction, VALU issue-slot utilisation, active lanes and occupancy"},
         }
+        if brief:
+            row = {"workload": cfg.workload, "frame": f"{WIDTH}x{HEIGHT}, {SPP_PER_STEP} spp per step", "ms_per_step": out["ms_per_step"],
+                   "mrays_per_s": out["value"], "mpaths_per_s": out["config"]["mpaths_per_s"],
+                   "reference_equivalent_mrays_s": out["config"]["reference_equivalent_mrays_s"],
+                   "triangles": scene.n_triangles(), "scene_load_s": round(scene_load_s, 3), "scene_commit_s": round(scene_commit_s, 3),
+                   "dominant_kernel": dom, "dominant_kernel_ms_per_step": d["ms_per_step"], "bound": bound,
+                   "roofline_frac_algorithmic": achieved / peak,
+                   "measured_util": d["hbm_traffic_frac"] if bound == "hbm" else d["valu_issue_util"],
+                   "active_lane_ratio": d["active_lane_ratio"], "pmc_summary": (pmc or {}).get("_meta", {}).get("file"),
+                   "kernel_ms_per_step": kernel_ms,
+                   "vs_oracle": psnr_vs_oracle(cfg, scene, r, 4 * cfg.cpu_tile_stride if cfg.cpu_tile_stride > 1 else 1)}
+            r.close()
+            return row
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, r)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        r.close()
+        return out
+    r.close()
+    return None
 
 
 if __name__ == "__main__":

@@ -297,12 +297,15 @@ int rt_render_accumulate(rt_context* ctx, const rt_render_params* params, void* 
 /* Final division, sRGB, Color24 (RayTracer.cpp:206-216) from a device accumulator. */
 int rt_resolve(rt_context* ctx, const rt_render_params* params, const void* d_accum, rt_framebuffer* fb);
 
-/* The frame's one exchange for multi-GPU hosts that do not use torch.distributed (the reference's host is C++): in-place
- * RCCL sum-reduce of a device accumulator (W*H*8 floats, layout above) to rank `root` of `nccl_comm` (an ncclComm_t the
- * caller created, one rank per GPU), on the context's stream; blocks until it has completed.  `nccl_reduce_fn` is the
- * caller's ncclReduce (pass `(void*)&ncclReduce`), or NULL to look it up among the process's global symbols — librtcore
- * does not link RCCL, so the communicator and the function always come from the same library.  The reference has no
- * counterpart (single process, RayTracer.cpp:41-50); SURVEY 8e defines the exchange. */
+/* The frame's one exchange for multi-GPU hosts that do not use torch.distributed (the reference's host is C++): RCCL
+ * sum-reduce of a device accumulator (W*H*8 floats, layout above) to rank `root` of `nccl_comm` (an ncclComm_t the caller
+ * created, one rank per GPU), on the context's stream; blocks until it has completed.  Floats 0..3 of every pixel (sum rgb,
+ * n: all a frame of partitioned samples or tiles needs) travel as a packed W*H*4 image — half the accumulator — and are
+ * written back into d_accum: the root then holds the sums, every other rank its own values; floats 4..7 (sums of squares,
+ * the adaptive sampler's done flag) are left alone on every rank.  `nccl_reduce_fn` is the caller's ncclReduce (pass
+ * `(void*)&ncclReduce`), or NULL to look it up among the process's global symbols — librtcore does not link RCCL, so the
+ * communicator and the function always come from the same library.  The reference has no counterpart (single process,
+ * RayTracer.cpp:41-50); SURVEY 8e defines the exchange. */
 int rt_reduce_accumulators(rt_context* ctx, void* nccl_comm, void* nccl_reduce_fn, void* d_accum, int32_t width, int32_t height, int root);
 
 /* GeneratePhotons (RayTracer.cpp:262-294): emission, random walk, both maps, balance. */
@@ -327,12 +330,14 @@ int rt_denoise(rt_context* ctx, const float* rgb_in, float* rgb_out, int32_t wid
                const float* albedo, const float* normal);
 
 /* rt_denoise without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate device
- * memory — code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same filter and kernels as
- * rt_denoise, but d_rgb_in / d_rgb_out / d_albedo / d_normal are DEVICE pointers (W*H*3 floats each, guides may be NULL)
+ * memory — tight serving loops, harnesses that forbid hipMalloc, hosts whose memory is fully planned.  Same filter and kernels
+ * as rt_denoise, but d_rgb_in / d_rgb_out / d_albedo / d_normal are DEVICE pointers (W*H*3 floats each, guides may be NULL)
  * and the filter's working images live in a fixed 64 MiB device array of the library (one copy per GPU, held until the
  * process ends) instead of allocated buffers.  Limit: width * height <= 1048576 pixels (RT_ERR_UNSUPPORTED beyond it).
- * Calls no hipMalloc / hipFree.  Blocks until the result is in d_rgb_out.  Every call on one GPU shares that GPU's
- * array: calls that overlap on one GPU (from several contexts or threads) race and must be serialised by the caller. */
+ * Calls no hipMalloc / hipFree.  It runs on the context's own stream and blocks until the result is in d_rgb_out (so it is
+ * not a call to make while a stream is being captured into a HIP graph); whatever produces d_rgb_in and the guides on
+ * another stream must have finished before the call (synchronise that stream first).  Every call on one GPU shares that
+ * GPU's array: calls that overlap on one GPU (from several contexts or threads) race and must be serialised by the caller. */
 int rt_denoise_noalloc(rt_context* ctx, const float* d_rgb_in, float* d_rgb_out, int32_t width, int32_t height,
                        const float* d_albedo, const float* d_normal);
 
@@ -356,6 +361,12 @@ int rt_set_option(rt_context* ctx, const char* name, double value);
  * buffers in the context and grow them only, so a steady-state caller sees this stand still (no counterpart in the
  * reference, whose renderer allocates per render, RayTracer.cpp:29-38). */
 int rt_debug_alloc_count(rt_context* ctx, uint64_t* n);
+
+/* The sampler as the kernels run it, for known-answer tests: Philox4x32-10 of `n` counters (4 words each, host) under the key
+ * (key_lo, key_hi) computed ON THE DEVICE -> the 4 output words per counter and their mapping to [0, 1) (RNG::RandomFloat's
+ * mapping, rng.h:60-65).  Philox replaces the reference's PCG32 streams (rng.h:29-99); a render uses counter =
+ * (pixel, tree node, block, tag) under the key (seed_lo, seed_hi). */
+int rt_debug_philox(rt_context* ctx, const uint32_t* counters, uint32_t key_lo, uint32_t key_hi, size_t n, uint32_t* words, float* units);
 
 /* Fills params with the reference's defaults (raytracer.h:17-23, renderer.h:172-174). */
 void rt_render_params_default(rt_render_params* params);

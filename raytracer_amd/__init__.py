@@ -351,6 +351,15 @@ class Renderer:
         """Developer knobs of this context (rt_set_option): tlas_min, gather_hints, frame_gb, fan_scale, timing."""
         self._check(self._lib.rt_set_option(self._ctx, name.encode(), float(value)), "rt_set_option")
 
+    def debug_philox(self, counters, key_lo, key_hi):
+        """rt_debug_philox: Philox4x32-10 of (n, 4) uint32 counters on the device -> (words (n, 4) uint32, units (n, 4) float32)."""
+        counters = np.ascontiguousarray(counters, dtype=np.uint32).reshape(-1, 4)
+        words = np.zeros_like(counters)
+        units = np.zeros(counters.shape, np.float32)
+        self._check(self._lib.rt_debug_philox(self._ctx, counters.ctypes.data, key_lo, key_hi, len(counters), words.ctypes.data,
+                                              units.ctypes.data), "rt_debug_philox")
+        return words, units
+
     def alloc_count(self):
         n = C.c_uint64()
         self._check(self._lib.rt_debug_alloc_count(self._ctx, C.byref(n)), "rt_debug_alloc_count")

@@ -204,7 +204,7 @@ CORE_SYMBOLS = [
     "rt_photons_build", "rt_photons_download", "rt_photons_set", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
     "rt_counters_reset", "rt_counters_get", "rt_profile_enable", "rt_profile_reset", "rt_profile_get",
     "rt_render_params_default", "rt_set_option", "rt_debug_alloc_count", "rt_denoise_noalloc", "rt_photons_download_tree", "rt_reduce_accumulators",
-    "rt_scene_mesh_bvh",
+    "rt_scene_mesh_bvh", "rt_debug_philox",
 ]
 HOST_SYMBOLS = [
     "rth_scene_load_file", "rth_scene_load_string", "rth_scene_free", "rth_last_error", "rth_scene_desc",
@@ -285,4 +285,5 @@ def bind_core(lib):
     lib.rt_reduce_accumulators.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int]
     lib.rt_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     lib.rt_debug_alloc_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.rt_debug_philox.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp]
     return lib

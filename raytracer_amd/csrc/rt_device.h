@@ -1279,7 +1279,9 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_
       }
       // P on or outside the sphere and every ray moving away from its centre
       const float bmin = pd - Rl * pl * 1.01f;
-      const bool leaving = bmin > 0.0f && (c >= 0.0f || (-c * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
+      // (c within rounding of 0 — P on the sphere — is held to the same margins whatever its sign: the per-ray test's own
+      //  c may differ from this one in the last ulps if the two sites are ever compiled differently)
+      const bool leaving = bmin > 0.0f && (c > 4e-7f * pp || (fabsf(c) * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
       free_of = beyond || leaving;
       if (touch && wmin > 0.0f) {
         const float sin_a = Rl * 1.01f * inv_dl;

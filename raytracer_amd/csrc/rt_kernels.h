@@ -1360,3 +1360,23 @@ RT_KERNEL(k_api_any, DScene S, const float* rays, const float* tmax, uint32_t n,
     out[i] = scene_any<false>(S, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), tmax ? tmax[i] : RT_BIG, stk, stride, cnt) ? 1 : 0;
   }
 }
+
+// rt_debug_philox: the sampler's generator and its float mapping as the kernels run them (known-answer tests)
+RT_KERNEL(k_debug_philox, const uint32_t* ctr, uint32_t k0, uint32_t k1, uint32_t n, uint32_t* words, float* units) {
+  for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) {
+    uint32_t r[4];
+    philox4x32_10(ctr[4 * (size_t)i], ctr[4 * (size_t)i + 1], ctr[4 * (size_t)i + 2], ctr[4 * (size_t)i + 3], k0, k1, r);
+    for (int k = 0; k < 4; k++) {
+      words[4 * (size_t)i + k] = r[k];
+      units[4 * (size_t)i + k] = u32_to_unit(r[k]);
+    }
+  }
+}
+
+// rt_reduce_accumulators: floats 0..3 of every pixel (sum rgb, n) to and from a packed image
+RT_KERNEL(k_acc_pack, const float4* accum, float4* packed, uint32_t n) {
+  for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) packed[i] = accum[2 * (size_t)i];
+}
+RT_KERNEL(k_acc_unpack, const float4* packed, float4* accum, uint32_t n) {
+  for (uint32_t i = RT_TID; i < n; i += RT_NTHREADS) accum[2 * (size_t)i] = packed[i];
+}

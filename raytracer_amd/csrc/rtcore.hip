@@ -120,7 +120,7 @@ struct Options {
 
 // grow-only device buffers the entry points reuse from call to call (no hipMalloc / hipFree in the steady state)
 enum { SC_ACCUM = 0, SC_RES_RGB, SC_RES_RAD, SC_RES_CNT, SC_API_A, SC_API_B, SC_API_C, SC_DN_RGB, SC_DN_A, SC_DN_B, SC_DN_ALB, SC_DN_NRM,
-       SC_PH, SC_KD, SC_COUNT };
+       SC_PH, SC_KD, SC_REDUCE, SC_COUNT };
 
 struct rt_context {
   int device = 0;
@@ -581,31 +581,23 @@ int rt_context_create(int device_id, rt_context** out) {
     ctx->max_blocks_trace = prop.multiProcessorCount * RT_TRACE_BLOCKS_PER_CU;  // re-sized per scene by rt_scene_commit
   }
 #endif
+  // every failure from here on leaves through ONE clean-up of whatever exists so far (rt_context_destroy copes with nulls)
+  auto fail_create = [&]() { rt_context_destroy(ctx); return RT_ERR_DEVICE; };
   void* p = nullptr;
-  if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) { delete ctx; return RT_ERR_DEVICE; }
+  if (hipMalloc(&p, sizeof(DCounters)) != hipSuccess) return fail_create();
   ctx->d_counters = (DCounters*)p;
-  (void)hipMemset(p, 0, sizeof(DCounters));
+  if (hipMemset(p, 0, sizeof(DCounters)) != hipSuccess) return fail_create();
   {  // per-pass summary (k_pass_summary): device words + their pinned host copy
     void *ds = nullptr, *hs = nullptr;
-    if (hipMalloc(&ds, 4096) != hipSuccess || hipHostMalloc(&hs, 4096) != hipSuccess) {
-      if (ds) (void)hipFree(ds);
-      (void)hipFree(p);
-      (void)hipStreamDestroy(ctx->stream);
-      delete ctx;
-      return RT_ERR_DEVICE;
-    }
+    if (hipMalloc(&ds, 4096) != hipSuccess) return fail_create();
     ctx->d_summary = (uint32_t*)ds;
+    if (hipHostMalloc(&hs, 4096) != hipSuccess) return fail_create();
     ctx->h_summary = (uint32_t*)hs;
   }
   {  // this device's address of the no-allocation entry point's working array (the device is current: hipSetDevice above)
 #ifndef RT_EMU
     void* sp = nullptr;
-    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
-      (void)hipFree(p);
-      (void)hipStreamDestroy(ctx->stream);
-      delete ctx;
-      return RT_ERR_DEVICE;
-    }
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) return fail_create();
     ctx->noalloc_ptr = (unsigned char*)sp;
 #else
     ctx->noalloc_ptr = scratch;
@@ -1050,6 +1042,24 @@ int rt_trace_closest(rt_context* ctx, const rt_ray* rays, size_t n, int hit_side
   LAUNCH_T(k_api_closest, n, ctx->ds, (const float*)d_r, (uint32_t)n, hit_side, (HitOut*)d_h);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hits, d_h, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_debug_philox(rt_context* ctx, const uint32_t* counters, uint32_t key_lo, uint32_t key_hi, size_t n, uint32_t* words, float* units) {
+  if (!ctx) return RT_ERR_INVALID;
+  quiesce(ctx);
+  if (n == 0) return RT_OK;
+  if (!counters || !words || !units || n > 0x0fffffffu) return fail(ctx, RT_ERR_INVALID, "bad counter batch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  void *d_c, *d_w, *d_u;
+  int rc;
+  if ((rc = grow_dev(ctx, SC_API_A, n * 16, &d_c)) || (rc = grow_dev(ctx, SC_API_B, n * 16, &d_w)) || (rc = grow_dev(ctx, SC_API_C, n * 16, &d_u))) return rc;
+  HIP_TRY(hipMemcpyAsync(d_c, counters, n * 16, hipMemcpyHostToDevice, ctx->stream));
+  LAUNCH(k_debug_philox, n, (const uint32_t*)d_c, key_lo, key_hi, (uint32_t)n, (uint32_t*)d_w, (float*)d_u);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(words, d_w, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(units, d_u, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
@@ -2272,8 +2282,22 @@ int rt_reduce_accumulators(rt_context* ctx, void* nccl_comm, void* nccl_reduce_f
   if (!fn) fn = (reduce_fn)dlsym(RTLD_DEFAULT, "ncclReduce");
   if (!fn) return fail(ctx, RT_ERR_UNSUPPORTED, "ncclReduce not found: link the host against librccl or pass the function pointer");
   const int nccl_float32 = 7, nccl_sum = 0;   // ncclFloat32 / ncclSum (nccl.h; stable ABI values)
-  int rc = fn(d_accum, d_accum, (size_t)width * (size_t)height * 8u, nccl_float32, nccl_sum, root, nccl_comm, ctx->stream);
-  if (rc != 0) return fail(ctx, RT_ERR_DEVICE, "ncclReduce failed with code " + std::to_string(rc));
+  // Sum rgb and n (floats 0..3 of every pixel) are all a frame of partitioned samples needs: they travel as a packed W*H*4
+  // image, half the accumulator.  Send and receive images are separate and the receive image starts as a copy of this rank's
+  // own values: ncclReduce writes it on the root only, so unpacking it afterwards gives the root the sums and every other
+  // rank its own values back — no rank has to know whether it is the root.
+  const size_t npx = (size_t)width * (size_t)height;
+  if (npx > 0x7fffffffu) return fail(ctx, RT_ERR_INVALID, "image too large");
+  void* buf = nullptr;
+  int rc = grow_dev(ctx, SC_REDUCE, 2 * npx * sizeof(float4), &buf);
+  if (rc) return rc;
+  float4 *send = (float4*)buf, *recv = send + npx;
+  LAUNCH(k_acc_pack, npx, (const float4*)d_accum, send, (uint32_t)npx);
+  HIP_TRY(hipMemcpyAsync(recv, send, npx * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  int nrc = fn(send, recv, npx * 4u, nccl_float32, nccl_sum, root, nccl_comm, ctx->stream);
+  if (nrc != 0) return fail(ctx, RT_ERR_DEVICE, "ncclReduce failed with code " + std::to_string(nrc));
+  LAUNCH(k_acc_unpack, npx, (const float4*)recv, (float4*)d_accum, (uint32_t)npx);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 #endif

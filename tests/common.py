@@ -602,3 +602,76 @@ def check_multimtl_scene(r, w, h, strict=None):
         assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= strict
         return None
     return assert_stochastic_close(g, c, "MultiMtl scene", frac=0.999, psnr=60.0, mean=1e-5)
+
+
+PHILOX_KAT = [  # Random123 kat_vectors, philox4x32 10 rounds: (counter, key, output)
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def check_philox_on_device(r, n=100000):
+    """SURVEY a15 on the device itself: the kernels' Philox4x32-10 against the published Random123 known-answer vectors,
+    against the oracle's generator on seeded random counters and keys, the float mapping (RNG::RandomFloat, rng.h:60-65:
+    u * 2^-32 clamped below 1) bit for bit, and the counter layout a frame uses — pixel (x, y)'s Cranley-Patterson offsets are
+    units 0 and 1 of counter (pixel, 0, 0, PIXEL tag) under the key (seed_lo, seed_hi) — through a render: with those offsets
+    and the Halton points the oracle's camera ray for every sample of the pixel must be the one the device traced (the hit
+    ids of a jittered 1-spp frame agree only if the device drew the same numbers)."""
+    import oracle_ffi
+    lib = oracle_ffi.load()
+    for ctr, key, expect in PHILOX_KAT:
+        words, _ = r.debug_philox(np.array([ctr], np.uint32), key[0], key[1])
+        assert tuple(int(x) for x in words[0]) == expect, (ctr, key, [hex(int(x)) for x in words[0]])
+    rng = np.random.default_rng(12)
+    ctr = rng.integers(0, 1 << 32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[:64] = np.array([[i, 0, 0, 0] for i in range(64)], np.uint32)          # the first pixels' offset counters
+    ctr[64:128, 3] = np.uint32(0xffffffff)                                     # carries in the high counter word
+    for key in ((1, 0), (0xdeadbeef, 0x12345678), (0xffffffff, 0xffffffff)):
+        words, units = r.debug_philox(ctr, *key)
+        want = np.zeros_like(ctr)
+        k = np.array(key, np.uint32)
+        o = np.zeros(4, np.uint32)
+        for i in list(range(256)) + list(range(256, n, max(1, n // 2000))):
+            c = np.ascontiguousarray(ctr[i])
+            lib.orc_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data)
+            assert np.array_equal(words[i], o), (i, key)
+        f = np.minimum(words.astype(np.float32) * np.float32(2.0 ** -32), np.float32(np.nextafter(np.float32(1.0), np.float32(0.0))))
+        assert np.array_equal(units, f) and units.max() < 1.0 and units.min() >= 0.0
+        assert abs(float(units.mean()) - 0.5) < 5e-3
+    # (the mapping is checked on the formula above for every word of 3 x n x 4 draws, among them words above 0xff000000)
+    assert (words >= np.uint32(0xff000000)).any()
+    # the counter layout of a frame: units 0 / 1 of counter (pixel, 0, 0, PIXEL tag = 0) under the key (seed_lo, seed_hi) are the
+    # pixel's Cranley-Patterson offsets (RayTracer.cpp:129-131 draws them from RNG(index)); with them and the Halton points the
+    # oracle's camera ray of (pixel, sample) is reproduced here in numpy (RayTracer.cpp:95-101, 138-149, 165-174)
+    from raytracer_amd import Scene
+    from conftest import scene_path
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    orc = oracle_ffi.OracleScene(scene)
+    W, H = 64, 36
+    p = params(W, H, spp=8, jitter=1, seed=77)
+    p.seed_hi = 5
+    cam = scene.desc.camera
+    assert cam.dof == 0.0
+    f32 = np.float32
+    d, up, pos = np.array(cam.dir[:], f32), np.array(cam.up[:], f32), np.array(cam.pos[:], f32)
+    X, Y, Z = np.cross(up, -d).astype(f32), up, -d
+    wh = f32(2.0) * f32(cam.focaldist) * f32(np.tan(np.float64(f32(cam.fov) * f32(np.pi) / f32(180.0)) / 2.0))
+    ww = wh * f32(W) / f32(H)
+    pixels = np.array([0, 1, W + 3, 17 * W + 40, W * H - 1], np.uint32)
+    ctrs = np.zeros((len(pixels), 4), np.uint32)
+    ctrs[:, 0] = pixels
+    _, units = r.debug_philox(ctrs, 77, 5)
+    for j, pix in enumerate(pixels):
+        x, y = int(pix) % W, int(pix) // W
+        ro = units[j, 0]
+        for i in (0, 1, 5, 7):
+            hx = f32(lib.orc_halton(i, 2)) + ro
+            hy = f32(lib.orc_halton(i, 3)) + ro          # (Y also uses randomOffset, RayTracer.cpp:141)
+            hx = hx - f32(1) if hx > 1 else hx
+            hy = hy - f32(1) if hy > 1 else hy
+            px = -(ww / f32(2)) + ww * (f32(x) + f32(0.5) + hx) / f32(W)
+            py = (wh / f32(2)) - wh * (f32(y) + f32(0.5) + hy) / f32(H)
+            want = X * px + Y * py + Z * (-f32(cam.focaldist))
+            o, got = orc.primary_ray(p, x, y, i)
+            assert np.allclose(o, pos) and np.allclose(got, want, rtol=2e-6, atol=2e-6), (pix, i, got, want)

@@ -178,8 +178,20 @@ def check_photon_maps_match_sequential_emitter(r, scene, n_photons=2000, emit_li
         if exact:
             assert ok.all(), f"map {which}: {np.count_nonzero(~ok)} photons differ in position"
         else:
-            print(f"photon map {which}: {ok.mean():.5f} of the photons identical")
+            # Attribution of the photons that differ (device sinf / cosf / powf vs libm in the last ulp): a photon of the
+            # oracle's map found at ANOTHER slot of the device's map belongs to a path that runs on identically but sits behind
+            # one whose number of deposits changed ("shifted"); one without a twin anywhere comes from a bounce where an ulp
+            # flipped a roulette or hit decision, or from a glancing bounce that magnifies the ulp ("diverged").
+            from scipy.spatial import cKDTree
+            bad = np.flatnonzero(~ok)
+            dist, _ = cKDTree(g["position"].astype(np.float64)).query(c["position"][bad].astype(np.float64), k=1)
+            shifted = int((dist <= 1e-3).sum())
+            diverged = len(bad) - shifted
+            out[f"map{which}"] = {"identical": float(ok.mean()), "shifted": shifted, "diverged": diverged}
+            print(f"photon map {which}: {ok.mean():.5f} of the photons identical in place; of the {len(bad)} others {shifted} are the "
+                  f"oracle's photons at another slot (a path before them changed its number of deposits), {diverged} have no twin")
             assert ok.mean() >= 0.995, f"map {which}: only {ok.mean():.3f} of the photons match"   # measured on MI355X: 0.9997 / 0.9985
+            assert diverged <= 0.002 * len(g), f"map {which}: {diverged} photons without a twin in the oracle's map"
         assert np.abs(g["dir"][ok] - c["dir"][ok]).max() <= 1e-3
         # (powers can be negative: mult = ks * dot(newDir, N) is not clamped, materials.cpp:372)
         rel = np.abs(g["power"][ok] - c["power"][ok]) / np.maximum(np.abs(c["power"][ok]), 1e-12)
@@ -188,7 +200,7 @@ def check_photon_maps_match_sequential_emitter(r, scene, n_photons=2000, emit_li
     return out
 
 
-def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=45.0, tol=2e-3):
+def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=80.0, tol=1e-5):
     """Whole frame with the photon term on (materials.cpp:315-322): global map on primary hits, caustics map on
     secondary hits.  The oracle gathers from the DEVICE's photons so that the comparison isolates gather + shading."""
     r.LoadScene(scene)
@@ -205,8 +217,9 @@ def check_photon_render(r, scene, n_photons=3000, w=64, h=36, spp=2, psnr_min=45
     q.photons = 0
     base = orc.render(q)
     assert np.abs(c.radiance[..., :3] - base.radiance[..., :3]).max() > 1e-2, "photon term contributes nothing"
-    assert psnr8(g.img, c.img) >= psnr_min
-    assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean() <= tol
+    mean = float(np.abs(g.radiance[..., :3] - c.radiance[..., :3]).mean())
+    print(f"photon frame: PSNR {psnr8(g.img, c.img):.1f} dB, mean |diff| {mean:.3g}")
+    assert psnr8(g.img, c.img) >= psnr_min and mean <= tol, (psnr8(g.img, c.img), mean)
     return g, c
 
 
@@ -295,3 +308,52 @@ def check_gather_bracket_search(r, scene):
         # ties among different photons are resolved by heap history in the reference: the sets may differ by the photons at
         # the k-th distance, never by more
         assert np.median(rel) <= 2e-5 and rel.max() <= 2.5 / k, f"identical photons, k={k}: {rel.max()}"
+
+
+def check_c4_as_defined(r, scene, w, h, n_photons=100000, k=128, spp=(32, 128), threshold=0.01, equal_frac=0.9995, tol_mean=1e-5, psnr_min=80.0,
+                        denoise_tol=2e-5):
+    """BASELINE config 4 end to end with the reference's own constants: two maps of numPhotons = 100000 (raytracer.h:23),
+    global map on primary and caustics map on secondary hits with k = 128, r = 3, e = 1 / 0.25 (materials.cpp:315-322),
+    adaptive 32..128 samples at threshold 0.01 (raytracer.h:20-21, RayTracer.cpp:180-198), three bounces, 16..128 soft-shadow
+    rays, then StopRender's post pass (RayTracer.cpp:64-83): the 8-bit frame re-floated, denoised, back to 8 bit.
+    The oracle gathers from the DEVICE's kd-trees (its own emitter's maps are compared in
+    check_photon_maps_match_sequential_emitter), so that the comparison covers gather + shading + the adaptive stop."""
+    from raytracer_amd import default_params
+    import oracle_ffi
+    r.LoadScene(scene)
+    p = default_params()                       # the reference's constants
+    assert (p.spp_min, p.spp_max, p.photons, p.n_photons, p.photon_k, p.max_bounces, p.shadow_min, p.shadow_max) == (32, 128, 1, 100000, 128, 3, 16, 128)
+    assert p.photon_radius == 3.0 and p.ellipticity_global == 1.0 and p.ellipticity_caustic == 0.25 and abs(p.adaptive_threshold - 0.01) < 1e-9
+    p.width, p.height = w, h
+    p.n_photons, p.photon_k = n_photons, k     # (the emulation test shrinks these; the GPU test passes the defaults)
+    p.spp_min, p.spp_max = spp
+    p.adaptive_threshold = threshold
+    g = r.Render(p)
+    orc = oracle_ffi.OracleScene(scene)
+    for which in (0, 1):
+        tree = r.GetPhotonTree(which)
+        assert len(tree) == n_photons and kd_tree_is_valid(tree)
+        orc.photons_set_tree(which, tree)
+    c, cnt = orc.render(p, want_counters=True)
+    assert cnt["gathers"] >= cnt["paths"] > w * h * spp[0]
+    assert c.sample_count.min() == spp[0] + 1 and c.sample_count.max() == spp[1] and len(np.unique(c.sample_count)) > 3
+    same = g.sample_count == c.sample_count
+    d = np.abs(g.radiance[..., :3] - c.radiance[..., :3])
+    stats = {"equal_counts": float(same.mean()), "mean": float(d[same].mean()), "max": float(d[same].max()), "psnr": float(psnr8(g.img, c.img)),
+             "mean_spp": float(c.sample_count.mean())}
+    assert np.array_equal(g.hit_node, c.hit_node), stats
+    assert same.mean() >= equal_frac, stats
+    assert stats["mean"] <= tol_mean and stats["psnr"] >= psnr_min, stats
+    # StopRender (RayTracer.cpp:64-83): Color24 -> Color, Denoise, -> Color24; the guides are the frame's own albedo / normal
+    # (the overload the reference declares, denoiser.h:16-17).  Device filter against its CPU restatement on the SAME input
+    # (OIDN's weights are absent: parity with the reference's denoiser is unpinned), and the two pipelines end to end.
+    to8 = lambda im: np.clip(im * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    gin = g.img.astype(np.float32) / np.float32(255.0)
+    gd = r.Denoise(gin, g.albedo, g.normal)
+    cd_same = oracle_ffi.denoise(gin, g.albedo, g.normal)
+    assert np.abs(gd - cd_same).max() <= denoise_tol, np.abs(gd - cd_same).max()
+    cd = oracle_ffi.denoise(c.img.astype(np.float32) / np.float32(255.0), c.albedo, c.normal)
+    stats["psnr_denoised"] = float(psnr8(to8(gd), to8(cd)))
+    assert stats["psnr_denoised"] >= 50.0, stats
+    assert np.abs(gd - gin).mean() > 1e-4, "the filter did nothing"
+    return stats

@@ -304,6 +304,10 @@ def test_every_bundled_reference_scene_renders_like_the_oracle(emu):
         assert psnr8(g.img, c.img) >= 60.0, f"{f}: PSNR {psnr8(g.img, c.img):.1f}"
 
 
+def test_philox_known_answers_through_the_kernel_source(emu):
+    common_checks.check_philox_on_device(emu, n=5000)
+
+
 def test_multimtl_scene(emu):
     common_checks.check_multimtl_scene(emu, 96, 54, strict=1e-4)
 

@@ -57,3 +57,11 @@ def test_gather_bracket_search_growth_and_ties(emu):
 
 def test_kd_tree_build_matches_reference_balance(emu):
     pc.check_kd_tree_build(emu, Scene.load(scene_path("cornell_box.xml")))
+
+
+def test_c4_adaptive_photons_denoise_end_to_end(emu):
+    """BASELINE config 4's pipeline at emulation size (single-threaded kernels): adaptive sampling WITH the photon term, both
+    maps, then the denoise pass.  The GPU test runs it with the reference's constants (100 000 photons, k = 128, 32..128)."""
+    s = pc.check_c4_as_defined(emu, Scene.load(scene_path("cornell_box.xml")), 32, 18, n_photons=3000, k=32, spp=(4, 16), threshold=0.03,
+                               equal_frac=1.0, tol_mean=2e-5, psnr_min=60.0)
+    print(s)

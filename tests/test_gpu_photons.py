@@ -26,6 +26,7 @@ def test_photon_maps_match_sequential_emitter(gpu_renderer):
     n = pc.check_photon_maps_match_sequential_emitter(gpu_renderer, Scene.load(scene_path("cornell_box.xml")),
                                                       n_photons=20000, exact=False)
     assert n[0] == 20000 and n[1] == 20000
+    print(n)
 
 
 def test_photon_maps_reference_size(gpu_renderer):
@@ -42,8 +43,17 @@ def test_photon_maps_reference_size(gpu_renderer):
 
 
 def test_photon_render(gpu_renderer):
+    """Gate = what the device achieves with margin (measured: > 90 dB, mean |diff| < 1e-6): PSNR >= 80 dB, mean <= 1e-5."""
     pc.check_photon_render(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000, w=240, h=135, spp=4,
-                           psnr_min=40.0)
+                           psnr_min=80.0, tol=1e-5)
+
+
+def test_c4_adaptive_photons_denoise_end_to_end(gpu_renderer):
+    """BASELINE config 4 as defined, with the reference's constants (2 x 100 000 photons, k = 128, r = 3, e = 1 / 0.25, adaptive
+    32..128 at 0.01, three bounces, 16..128 shadow rays, then the denoise pass), against the oracle gathering from the
+    device's trees: sample counts equal for >= 99.95 % of the pixels, radiance and the denoised 8-bit frame compared."""
+    s = pc.check_c4_as_defined(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), 160, 90)
+    print("c4 as defined:", s)
 
 
 def test_gather_hints_change_walks_only(gpu_renderer):

@@ -5,7 +5,7 @@ import pytest
 import oracle_ffi
 import os
 
-from common import assert_stochastic_close, check_edge_cases, check_random_scene_graphs, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
+from common import assert_stochastic_close, check_edge_cases, check_philox_on_device, check_random_scene_graphs, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
 from conftest import ROOT, scene_path
 from raytracer_amd import Scene
 
@@ -73,6 +73,37 @@ def test_sample_ranges_sum_to_full_render(gpu_renderer):
     assert (split.radiance[..., 3] == 8).all()
 
 
+def test_tile_split_accumulate_equals_full_frame(gpu_renderer):
+    """Multi-GPU tile split: ranks render 32x32 tiles r, r + G, ... (tile_begin / tile_stride) into their own
+    accumulators; the sum of the accumulators is EXACTLY the full frame's (disjoint pixels, every pixel by one rank) — two and
+    three virtual ranks on one GPU, a mesh scene with three bounces, ragged frame size (partial tiles)."""
+    import torch
+    scene = Scene.load(scene_path("c2_mesh_room.xml"))
+    gpu_renderer.LoadScene(scene)
+    W, H = 328, 200
+    p = params(W, H, spp=4, jitter=1, bounces=3)
+    full = gpu_renderer.Render(p)
+    for G in (2, 3):
+        accs = []
+        for rank in range(G):
+            acc = torch.zeros(W * H * 8, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            q = params(W, H, spp=4, jitter=1, bounces=3)
+            q.tile_begin, q.tile_stride = rank, G
+            gpu_renderer.render_accumulate(q, acc.data_ptr())
+            torch.cuda.synchronize()
+            accs.append(acc)
+        n = torch.stack([a.view(H, W, 8)[..., 3] for a in accs])
+        assert ((n > 0).sum(dim=0) == 1).all(), "a pixel was rendered by no rank or by two"
+        total = torch.stack(accs).sum(dim=0)          # what ncclReduce(sum) leaves on the root
+        torch.cuda.synchronize()
+        img = gpu_renderer.resolve(p, total.data_ptr())
+        assert (img.radiance[..., 3] == 4).all()
+        # (float atomics into a path's radiance slot are unordered run to run: equal to the order of those sums)
+        assert np.allclose(img.radiance[..., :3], full.radiance[..., :3], rtol=1e-5, atol=1e-6)
+        assert (img.img == full.img).mean() > 0.9995
+
+
 def test_geometry_buffers_match_oracle(gpu_renderer):
     """rt_framebuffer depth / normal / albedo (RenderImage::zbuffer, renderer.h:39; Denoise guides, denoiser.h:16-17)."""
     check_geometry_buffers(gpu_renderer, Scene.load(scene_path("c2_mesh_room.xml")), 480, 270)
@@ -89,3 +120,8 @@ def test_edge_cases(gpu_renderer):
 
 def test_random_scene_graphs(gpu_renderer):
     check_random_scene_graphs(gpu_renderer, seeds=(1, 2, 3, 4, 5, 6), n_rays=20000, w=192, h=128)
+
+
+def test_philox_known_answers_on_the_device(gpu_renderer):
+    """the kernels' Philox4x32-10 and float mapping on the MI355X against the Random123 vectors and the oracle."""
+    check_philox_on_device(gpu_renderer)

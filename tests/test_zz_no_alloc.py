@@ -24,9 +24,13 @@ def test_denoise_noalloc_matches_rt_denoise(gpu_renderer):
         d_in, d_out = _dev(noisy), torch.full((h, w, 3), -7.0, dtype=torch.float32, device="cuda:0")
         d_a = _dev(a) if guides else None
         d_n = _dev(n) if guides else None
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()       # (the inputs' producer stream must have finished before the call, include/rtcore.h)
         before = r.alloc_count()
+        free_before = torch.cuda.mem_get_info(0)[0]     # hipMemGetInfo: the DEVICE's free memory, whoever allocates
         r.denoise_noalloc(d_in.data_ptr(), d_out.data_ptr(), w, h, d_a.data_ptr() if guides else 0, d_n.data_ptr() if guides else 0)
+        # the library's own counter only sees the allocation sites that bump it; the device's free memory sees any hipMalloc
+        # (or lazily allocating call) made on the way — it must stand still across the call
+        assert torch.cuda.mem_get_info(0)[0] == free_before, "device memory was allocated or freed during rt_denoise_noalloc"
         assert r.alloc_count() == before
         got = d_out.cpu().numpy()
         assert np.array_equal(got, want), f"{w}x{h}: differs from rt_denoise by {np.abs(got - want).max()}"
