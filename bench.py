@@ -141,6 +141,10 @@ CONFIGS = {
     "spheres": Config("spheres", "scene-graph stress (stand-in for the reference's scenes/volumetric_spiral.xml): 2944 glass spheres under "
                       "one group node + floor sphere, point light of size 0, 3 bounces reflection + refraction", 1920, 1080, 4, _sphere_field,
                       lambda p: None, cpu_tile_stride=16),
+    "finalproject": Config("finalproject", "the scene the reference's main.cpp:12 hard-codes (scenes/finalProject.xml as the data fixture "
+                           "tests/golden/scenes/ref_finalProject.xml: 5 walls, 64 glass spheres in 4 rotated rings, a procedural teapot for the "
+                           "absent teapot.obj, sphere lights of size 4 and 8), 3 bounces, soft shadows 16..128 rays, photons off", 1920, 1080, 8,
+                           _load("tests/golden/scenes/ref_finalProject.xml"), lambda p: None, cpu_tile_stride=16),
     "c5": Config("c5", "C5: synthetic stress scene, 12.6 M triangles in one BVH (2048 icospheres + displaced ground), 2 sphere "
                  "lights, 3 bounces; 4 of the 4096 spp per step", 3840, 2160, 4, _stress, lambda p: None, cpu_tile_stride=509),
 }
@@ -247,6 +251,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (c2, one GPU): skip the short runs of the other configurations")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--soft-clear", type=int, default=1, help="0: trace every soft-shadow group (no clear-view / full-shadow proofs)")
     ap.add_argument("--device-bvh", action="store_true", help="mesh BVHs built at rt_scene_commit on the device instead of by the host loader")
     args = ap.parse_args()
     HOST_BVH = not args.device_bvh
@@ -281,7 +286,7 @@ def main():
             # every other BASELINE configuration (and the scene-graph stress case) in the same driver-run line: short runs
             # (1 warm-up + 3 steps each), compact rows; their long CPU rows stay in profiles/ and BASELINE.md
             out["config"]["other_configs"] = {}
-            for name in ("c1", "c3", "c4", "c5", "spheres"):
+            for name in ("c1", "c3", "c4", "c5", "spheres", "finalproject"):
                 short = argparse.Namespace(**vars(args))
                 short.steps, short.warmup = 3, 1
                 t0 = time.perf_counter()
@@ -331,6 +336,7 @@ def run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief):
     scene = cfg.scene()       # host: XML / generator, meshes, BVH build
     scene_load_s = time.perf_counter() - t0
     r = Renderer(local_rank)
+    r.set_option("soft_clear", args.soft_clear)
     t0 = time.perf_counter()
     r.LoadScene(scene)        # rt_scene_commit: device layout + upload
     scene_commit_s = time.perf_counter() - t0

@@ -1212,91 +1212,172 @@ RT_DEV float rt_fast_sqrt(float x) { return sqrtf(x); }
 #define RT_CONE_TRACE 0
 #define RT_CONE_CLEAR 1
 #define RT_CONE_UMBRA 2
+// The group's cone: rays from P to the points within R of C (a = C - P).
+struct Cone {
+  V3 P, a, ainv;
+  float len, R, s_max, Rw;
+  bool ainv_finite, sized;
+};
+RT_DEV Cone cone_of(V3 P, V3 C, float R, bool active) {
+  Cone K;
+  K.P = P; K.R = R;
+  K.a = C - P;
+  K.len = rt_fast_sqrt(dot(K.a, K.a));
+  K.sized = active && K.len > 2.0f * R && K.len < 1e30f;   // (a shade point inside or next to the light itself: trace)
+  K.ainv = v3(rt_fast_rcp(K.a.x), rt_fast_rcp(K.a.y), rt_fast_rcp(K.a.z));
+  K.ainv_finite = fabsf(K.ainv.x) <= RT_BIG && fabsf(K.ainv.y) <= RT_BIG && fabsf(K.ainv.z) <= RT_BIG;
+  K.s_max = 1.0f + 1.01f * R * rt_fast_rcp(K.len > 0.0f ? K.len : 1.0f) + 1e-3f;   // rays end at most R beyond C
+  K.Rw = R * 1.002f + 1e-4f;
+  return K;
+}
+// Does the cone's axis segment touch the box grown by the cone's radius?  (A segment parallel to an axis has an infinite
+// reciprocal, and 0 x inf in a slab is NaN: no box is skipped on that.)
+RT_DEV bool cone_touches_box(const Cone& K, float lx, float ly, float lz, float hx, float hy, float hz) {
+  float tm;
+  return !K.ainv_finite || (box_test(K.P, K.ainv, lx - K.Rw, ly - K.Rw, lz - K.Rw, hx + K.Rw, hy + K.Rw, hz + K.Rw, tm) && !(tm > K.s_max));
+}
+// One sphere (prim 1) or plane (prim 2) against the cone, in the instance's space: p, d = P and C - P there (the same
+// transforms, in the same order, as the rays' own: P lands on the very floats the per-ray tests see), `grow` a bound on how
+// far a unit world length reaches there (chain_stretch, computed at commit).  Returns true when no ray of the cone can be
+// occluded by the instance; sets `umbra` when every ray is.
+RT_DEV bool cone_free_of(const Cone& K, int prim, V3 p, V3 d, float grow, bool touch, bool& umbra) {
+  const float len = K.len, R = K.R, s_max = K.s_max;
+  const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+  const float slack = 1e-5f * (1.0f + mag);
+  const float Rg = R * grow * 1.002f;   // the cone's radius at the light, in this space
+  const float Rl = Rg + slack;
+  if (prim == 2) {
+    const float z0 = p.z;
+    const float wlo = d.z - Rl, whi = d.z + Rl;   // z of the rays' end points relative to P's
+    const float amin = wlo > 0.0f ? wlo : (whi < 0.0f ? -whi : 0.0f), amax = fmaxf(fabsf(wlo), fabsf(whi));
+    const bool same_side = (z0 >= 0.0f && wlo > 0.0f) || (z0 <= 0.0f && whi < 0.0f);
+    const bool too_near = amin >= fabsf(z0) * (len + R) * (1.01f / 0.0002f) + 1e-7f;   // t = |z0| / |d.z| <= 0.0002
+    const bool not_reached = amax <= 0.99f * fabsf(z0);                                // t >= t_max
+    // full shadow of the plane: every ray crosses z = 0 (P on one side, every end point on the other) between the test's
+    // t > 0.0002 and its light sample (s* = |z0| / |w.z| in [s_lo, s_hi], t = s* |w_world|, t_max at s = 1), and every crossing
+    // point p.xy + s* w.xy, w.xy within Rl of d.xy, lies inside the unit square the test accepts (objects.cpp:152-167)
+    if (touch && amin > 0.0f && !same_side) {
+      const float s_lo = fabsf(z0) * rt_fast_rcp(amax) * 0.999f, s_hi = fabsf(z0) * rt_fast_rcp(amin) * 1.001f;
+      const bool crosses = s_hi <= 0.99f && s_lo * (len - R) > 0.000202f;
+      const float xa = d.x - Rl, xb = d.x + Rl, ya = d.y - Rl, yb = d.y + Rl;
+      const float x_min = p.x + fminf(s_lo * xa, s_hi * xa), x_max = p.x + fmaxf(s_lo * xb, s_hi * xb);
+      const float y_min = p.y + fminf(s_lo * ya, s_hi * ya), y_max = p.y + fmaxf(s_lo * yb, s_hi * yb);
+      if (crosses && x_min >= -0.999f && x_max <= 0.999f && y_min >= -0.999f && y_max <= 0.999f) umbra = true;
+    }
+    return same_side || too_near || not_reached;
+  }
+  const float dd = dot(d, d), pd = dot(p, d), pp = dot(p, p);
+  const float dl = rt_fast_sqrt(dd), pl = rt_fast_sqrt(pp), c = pp - 1.0f;
+  const float inv_dd = rt_fast_rcp(dd), inv_dl = rt_fast_rcp(dl);
+  const float wmax = dl + Rl, wmin = dl - Rl;   // lengths of the rays here (s = 1 at their light sample)
+  // the cone's radius where it could touch: no farther along than where the axis leaves the sphere grown by the
+  // radius at the far end
+  float sn = dd > 0.0f ? -pd * inv_dd : 0.0f;
+  sn = fminf(fmaxf(sn, 0.0f), s_max);
+  const float reach0 = 1.0f + s_max * Rg + slack;
+  const V3 q0 = p + d * sn;
+  bool beyond = dot(q0, q0) > reach0 * reach0 * 1.001f;
+  if (!beyond && dd > 0.0f) {
+    const float disc = pd * pd - dd * (pp - reach0 * reach0);
+    float s_hi = disc > 0.0f ? (-pd + rt_fast_sqrt(disc)) * inv_dd * 1.001f + 1e-6f : s_max;
+    s_hi = fminf(fmaxf(s_hi, 0.0f), s_max);
+    const float reach1 = 1.0f + s_hi * Rg + slack;
+    const V3 q1 = p + d * fminf(sn, s_hi);
+    beyond = dot(q1, q1) > reach1 * reach1 * 1.001f;
+  }
+  // P on or outside the sphere and every ray moving away from its centre
+  const float bmin = pd - Rl * pl * 1.01f;
+  // (c within rounding of 0 — P on the sphere — is held to the same margins whatever its sign: the per-ray test's own
+  //  c may differ from this one in the last ulps if the two sites are ever compiled differently)
+  const bool leaving = bmin > 0.0f && (c > 4e-7f * pp || (fabsf(c) * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
+  if (touch && wmin > 0.0f) {
+    const float sin_a = Rl * 1.01f * inv_dl;
+    // (b) another sphere in front of the whole light
+    const V3 cr = cross(p, d);
+    const float sin_f = rt_fast_sqrt(dot(cr, cr)) * inv_dl * 1.0001f;   // (x |p| below: sin f |p| against 0.99)
+    const bool covers = pd < 0.0f && pl > 1.0f && sin_f + sin_a * pl < 0.99f && (pl - 1.0f) * (len - R) > 0.02f * wmax && pl < 0.99f * wmin;
+    // (a) the sphere P is on, rays going in: the far root 2 |p.w| / w.w, bounded from both sides
+    const float bneg = -(pd + Rl * pl * 1.01f), bpos = -pd + Rl * pl * 1.01f;
+    const bool through = bneg > 0.0f && fabsf(c) * wmax * wmax <= 0.01f * bneg * bneg && 1.99f * bneg * (len - R) > 0.02f * wmax * wmax &&
+                         2.01f * bpos < 0.99f * wmin * wmin;
+    if (covers || through) umbra = true;
+  }
+  return beyond || leaving;
+}
 // `may_occlude`: bit i = table entry i (< 32) could not be excluded for this group's rays (any_instances<.., MASKED>).
 RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_t& may_occlude) {
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
-  const V3 a = C - P;
-  const float len = rt_fast_sqrt(dot(a, a));
-  const bool sized = active && len > 2.0f * R && len < 1e30f;   // (a shade point inside or next to the light itself: trace)
+  const Cone K = cone_of(P, C, R, active);
+  const bool sized = K.sized;
   bool clear = sized, umbra = false;
   may_occlude = sized ? 0u : 0xFFFFFFFFu;
-  const V3 ainv = v3(rt_fast_rcp(a.x), rt_fast_rcp(a.y), rt_fast_rcp(a.z));
-  const bool ainv_finite = fabsf(ainv.x) <= RT_BIG && fabsf(ainv.y) <= RT_BIG && fabsf(ainv.z) <= RT_BIG;
-  const float s_max = 1.0f + 1.01f * R * rt_fast_rcp(len > 0.0f ? len : 1.0f) + 1e-3f;   // rays end at most R beyond C
-  const float Rw = R * 1.002f + 1e-4f;
   ParentRay pr;
-  pr.key = -2; pr.p = P; pr.d = a;
+  pr.key = -2; pr.p = P; pr.d = K.a;
   for (int i = 0; i < S.n_inst; i++) {
     RT_UTYPE(DInstance)* I = inst + i;
-    float tm;
-    // (a segment parallel to an axis has an infinite reciprocal, and 0 x inf in a slab is NaN: no box is skipped on that)
-    const bool touch = sized && !umbra && (!ainv_finite || (box_test(P, ainv, I->wmin[0] - Rw, I->wmin[1] - Rw, I->wmin[2] - Rw, I->wmax[0] + Rw,
-                                                                     I->wmax[1] + Rw, I->wmax[2] + Rw, tm) && !(tm > s_max)));
+    const bool touch = sized && !umbra && cone_touches_box(K, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2]);
     const int prim = I->prim;
     if (!wave_any(touch)) continue;   // [wave-uniform]
     if (prim == 3) {
       if (touch) { clear = false; if (i < 32) may_occlude |= 1u << i; }
       continue;
     }
-    // the segment in the instance's space (the same transforms, in the same order, as the rays' own: P lands on the
-    // very floats the per-ray tests see), and a bound on how far R reaches there (chain_stretch, computed at commit)
     V3 p, d;
-    ray_to_instance(I, xf, P, a, pr, p, d);
-    const float grow = I->stretch;
-    const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
-    const float slack = 1e-5f * (1.0f + mag);
-    const float Rg = R * grow * 1.002f;   // the cone's radius at the light, in this space
-    const float Rl = Rg + slack;
-    bool free_of = false;
-    if (prim == 2) {
-      const float z0 = p.z;
-      const float wlo = d.z - Rl, whi = d.z + Rl;   // z of the rays' end points relative to P's
-      const float amin = wlo > 0.0f ? wlo : (whi < 0.0f ? -whi : 0.0f), amax = fmaxf(fabsf(wlo), fabsf(whi));
-      const bool same_side = (z0 >= 0.0f && wlo > 0.0f) || (z0 <= 0.0f && whi < 0.0f);
-      const bool too_near = amin >= fabsf(z0) * (len + R) * (1.01f / 0.0002f) + 1e-7f;   // t = |z0| / |d.z| <= 0.0002
-      const bool not_reached = amax <= 0.99f * fabsf(z0);                                // t >= t_max
-      free_of = same_side || too_near || not_reached;
-    } else {
-      const float dd = dot(d, d), pd = dot(p, d), pp = dot(p, p);
-      const float dl = rt_fast_sqrt(dd), pl = rt_fast_sqrt(pp), c = pp - 1.0f;
-      const float inv_dd = rt_fast_rcp(dd), inv_dl = rt_fast_rcp(dl);
-      const float wmax = dl + Rl, wmin = dl - Rl;   // lengths of the rays here (s = 1 at their light sample)
-      // the cone's radius where it could touch: no farther along than where the axis leaves the sphere grown by the
-      // radius at the far end
-      float sn = dd > 0.0f ? -pd * inv_dd : 0.0f;
-      sn = fminf(fmaxf(sn, 0.0f), s_max);
-      const float reach0 = 1.0f + s_max * Rg + slack;
-      const V3 q0 = p + d * sn;
-      bool beyond = dot(q0, q0) > reach0 * reach0 * 1.001f;
-      if (!beyond && dd > 0.0f) {
-        const float disc = pd * pd - dd * (pp - reach0 * reach0);
-        float s_hi = disc > 0.0f ? (-pd + rt_fast_sqrt(disc)) * inv_dd * 1.001f + 1e-6f : s_max;
-        s_hi = fminf(fmaxf(s_hi, 0.0f), s_max);
-        const float reach1 = 1.0f + s_hi * Rg + slack;
-        const V3 q1 = p + d * fminf(sn, s_hi);
-        beyond = dot(q1, q1) > reach1 * reach1 * 1.001f;
-      }
-      // P on or outside the sphere and every ray moving away from its centre
-      const float bmin = pd - Rl * pl * 1.01f;
-      // (c within rounding of 0 — P on the sphere — is held to the same margins whatever its sign: the per-ray test's own
-      //  c may differ from this one in the last ulps if the two sites are ever compiled differently)
-      const bool leaving = bmin > 0.0f && (c > 4e-7f * pp || (fabsf(c) * (len + R) <= 0.004f * bmin && 4e-7f * pl * len <= 0.002f * dl));
-      free_of = beyond || leaving;
-      if (touch && wmin > 0.0f) {
-        const float sin_a = Rl * 1.01f * inv_dl;
-        // (b) another sphere in front of the whole light
-        const V3 cr = cross(p, d);
-        const float sin_f = rt_fast_sqrt(dot(cr, cr)) * inv_dl * 1.0001f;   // (x |p| below: sin f |p| against 0.99)
-        const bool covers = pd < 0.0f && pl > 1.0f && sin_f + sin_a * pl < 0.99f && (pl - 1.0f) * (len - R) > 0.02f * wmax && pl < 0.99f * wmin;
-        // (a) the sphere P is on, rays going in: the far root 2 |p.w| / w.w, bounded from both sides
-        const float bneg = -(pd + Rl * pl * 1.01f), bpos = -pd + Rl * pl * 1.01f;
-        const bool through = bneg > 0.0f && fabsf(c) * wmax * wmax <= 0.01f * bneg * bneg && 1.99f * bneg * (len - R) > 0.02f * wmax * wmax &&
-                             2.01f * bpos < 0.99f * wmin * wmin;
-        if (covers || through) umbra = true;
-      }
-    }
+    ray_to_instance(I, xf, P, K.a, pr, p, d);
+    const bool free_of = cone_free_of(K, prim, p, d, I->stretch, touch, umbra);
     if (touch && !free_of) { clear = false; if (i < 32) may_occlude |= 1u << i; }
+  }
+  return umbra ? RT_CONE_UMBRA : (clear ? RT_CONE_CLEAR : RT_CONE_TRACE);
+}
+// The same proofs for scenes whose rays walk the instance BVH (more instances than a linear table walk per group is worth):
+// every lane takes its cone through the BVH over the instances' padded world boxes — a node is entered when the cone's
+// axis touches its box grown by the cone's radius, exactly the per-instance box rule above, so an instance is looked at
+// iff the table walk would have looked at it — and applies the per-primitive rules at the leaves.  A walk that has not
+// ended after RT_CONE_STEPS node visits gives up (the group is traced): cones along a wall of instances would otherwise
+// cost more than the rays they might save.
+#ifndef RT_CONE_STEPS
+#define RT_CONE_STEPS 96
+#endif
+RT_DEV int cone_clear_tlas(const DScene& S, V3 P, V3 C, float R, bool active, uint32_t* stk, uint32_t stride) {
+  const Cone K = cone_of(P, C, R, active);
+  if (!K.sized) return RT_CONE_TRACE;
+  bool clear = true, umbra = false;
+  uint32_t cur = S.tlas_root;
+  int sp = 0, steps = 0;
+  for (;;) {
+    if (cur & RT_LEAF) {
+      const uint32_t count = cur & 7u, first = (cur & 0x7fffffffu) >> 3;
+      for (uint32_t s = 0; s < count && !umbra; s++) {
+        const int i = S.tlas_idx[first + s];
+        const DInstance* I = S.inst + i;
+        if (!cone_touches_box(K, I->wmin[0], I->wmin[1], I->wmin[2], I->wmax[0], I->wmax[1], I->wmax[2])) continue;
+        const int prim = I->prim;
+        if (prim == 3) { clear = false; continue; }   // a mesh whose grown box the axis touches is taken to occlude
+        V3 p, d;
+        ray_to_instance_full(I, S.xf, P, K.a, p, d);
+        if (!cone_free_of(K, prim, p, d, I->stretch, true, umbra)) clear = false;
+      }
+      if (umbra || sp == 0) break;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    if (++steps > RT_CONE_STEPS) return RT_CONE_TRACE;
+    const float4 n0 = S.tlas[4 * cur], n1 = S.tlas[4 * cur + 1], n2 = S.tlas[4 * cur + 2], n3 = S.tlas[4 * cur + 3];
+    const bool hl = cone_touches_box(K, n0.x, n1.x, n2.x, n0.z, n1.z, n2.z);
+    const bool hr = cone_touches_box(K, n0.y, n1.y, n2.y, n0.w, n1.w, n2.w);
+    const uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+    if (hl && hr) {
+      stk[(sp++) * stride] = cr;
+      cur = cl;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      if (sp == 0) break;
+      cur = stk[(--sp) * stride];
+    }
   }
   return umbra ? RT_CONE_UMBRA : (clear ? RT_CONE_CLEAR : RT_CONE_TRACE);
 }

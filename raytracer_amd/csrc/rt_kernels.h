@@ -1175,8 +1175,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
 // k_shadow_soft_decide adds it for a group whose shadow_min rays all came through (vis = 1).  Groups in the full shadow of
 // a sphere contribute vis = 0 (k_shadow_soft_final's 0 / shadow_max): nothing is added.  The others are listed for the
 // sample phases.
-template <bool CNT>
+template <bool CNT, bool TLAS>
 RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_t* list1, uint32_t* n1) {
+  RT_STACK_DECL
   uint32_t proven = 0;
   RT_SEG_BEGIN(G.counts, G.nseg, G.segcap, 1u)
     uint32_t g = seg_base_ + (uint32_t)seg_e;
@@ -1189,8 +1190,10 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
       C = v3(L.position[0], L.position[1], L.position[2]);
       R = G.g3[g].w;
     }
-    uint32_t may_occlude;
-    const int view = cone_clear(S, Pp, C, R, seg_valid, may_occlude);
+    uint32_t may_occlude = 0xFFFFFFFFu;
+    int view;
+    if (TLAS) view = seg_valid ? cone_clear_tlas(S, Pp, C, R, true, stk, stride) : RT_CONE_TRACE;   // (per lane: the instance BVH)
+    else view = cone_clear(S, Pp, C, R, seg_valid, may_occlude);                                    // (every lane: wave-uniform table walk)
     if (seg_valid && view == RT_CONE_CLEAR) {
       const float4 g1 = G.g1[g];
       add_radiance(F, __float_as_uint(g1.w), v3(g1.x, g1.y, g1.z) * 1.0f);

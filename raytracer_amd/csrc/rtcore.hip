@@ -116,6 +116,8 @@ struct Options {
   double fan_scale = 1;            // "fan_scale"    RT_TEST_FAN_SCALE  scales the measured queue sizing (tests: forces overflow)
   double timing = 0;               // "timing"       RT_TIMING        host-side phases of the photon build on stderr
   double soft_clear = 1;           // "soft_clear"   RT_SOFT_CLEAR    0: trace every soft-shadow group (tests compare both)
+  double cone_max_inst = RT_CONE_MAX_INST;   // "cone_max_inst"  instances up to which the soft-shadow proofs walk the instance table; beyond it
+                                             //                  (with an instance BVH) every group's cone walks the BVH (tests force both)
 };
 
 // grow-only device buffers the entry points reuse from call to call (no hipMalloc / hipFree in the steady state)
@@ -625,6 +627,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "fan_scale") { ctx->opt.fan_scale = value; ctx->fan_valid = false; }
   else if (n == "timing") ctx->opt.timing = value;
   else if (n == "soft_clear") ctx->opt.soft_clear = value;
+  else if (n == "cone_max_inst") ctx->opt.cone_max_inst = value;
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
   return RT_OK;
 }
@@ -1765,14 +1768,16 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       MeshQ MS1 = meshq(ctx->MS, lvl, CNT_MS1, CUR_MS1), MS2 = meshq(ctx->MS, lvl, CNT_MS2, CUR_MS2);
       const uint64_t ms_cap = (uint64_t)MS1.segcap * MS1.nseg;
       // groups with a clear view of their whole light are fully lit, groups in a sphere's full shadow dark, without a ray
-      // (the proof walks the instance table: one box test per instance for most; scenes of more than RT_CONE_MAX_INST
-      // instances trace every group)
-      const bool clear_first = ctx->opt.soft_clear != 0 && ctx->ds.n_inst <= RT_CONE_MAX_INST;
+      // (the proof walks the instance table — one box test per instance for most — or, in scenes of more than
+      // RT_CONE_MAX_INST instances, the instance BVH with the cone in place of a ray)
+      const bool cone_table = ctx->ds.n_inst <= (int)ctx->opt.cone_max_inst;
+      const bool clear_first = ctx->opt.soft_clear != 0 && (cone_table || ctx->ds.use_tlas);
       uint32_t* n1 = ctx->d_counts + cnt_at(lvl, CNT_N1);
       const uint32_t* list1 = clear_first ? ctx->d_list1 : nullptr;
       {
         Timer t(ctx, RT_K_SHADOW);
-        if (clear_first) LAUNCH_P1((k_shadow_soft_clear<CNT>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
+        if (clear_first && cone_table) LAUNCH_P1((k_shadow_soft_clear<CNT, false>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
+        else if (clear_first) LAUNCH_T((k_shadow_soft_clear<CNT, true>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
         if (ctx->ds.use_tlas)
           LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, list1, (const uint32_t*)(list1 ? n1 : nullptr), 0u,
                    (uint32_t)P.shadow_min, MS1);

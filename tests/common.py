@@ -514,13 +514,45 @@ def check_soft_shadow_clear_view_random(r, seeds, w, h, strict=None, tol=2e-6):
         tot1 = tot0 = 0
         for seed in seeds:
             r.set_option("tlas_min", 1000000 if seed % 2 else 2)   # (rays through the instance table / the instance BVH)
+            # with the instance BVH, every other scene's proofs walk that BVH too (cone_clear_tlas) instead of the table
+            r.set_option("cone_max_inst", 0 if seed % 4 == 0 else 64)
             xml = random_scene_xml(seed, width=w, height=h, light_size=(0.5, 1.5, 3.0)[seed % 3])
             n1, n0 = check_soft_shadow_clear_view(r, Scene.from_string(xml), w, h, strict=strict, tol=tol, min_saved=-1.0, gate=gate)
             tot1, tot0 = tot1 + n1, tot0 + n0
     finally:
         r.set_option("tlas_min", 24)
+        r.set_option("cone_max_inst", 64)
     assert tot1 < 0.9 * tot0
     return tot1, tot0
+
+
+def check_soft_shadow_proofs_many_instances(r, w, h, strict=None, tol=2e-6):
+    """Scenes of more than 64 instances: the proofs walk the instance BVH with the group's cone (cone_clear_tlas).  The
+    reference's own showcase scene (main.cpp:12: finalProject.xml, 70 instances, two lights of size 4 and 8; fixture with a
+    procedural teapot) and a Cornell box walked both ways (table / BVH): the frame with the proofs is the traced frame, rays
+    are saved, and the two walks prove the same groups."""
+    import os
+    from conftest import GOLDEN, ROOT, scene_path
+    from raytracer_amd import Scene
+    fp = Scene.load(os.path.join(GOLDEN, "scenes", "ref_finalProject.xml"), asset_dir=ROOT)
+    assert fp.desc.n_nodes > 70
+    gate = dict(frac=0.999, psnr=60.0, mean=1e-5)
+    n1, n0 = check_soft_shadow_clear_view(r, fp, w, h, strict=strict, tol=tol, min_saved=0.3, gate=gate, bounces=2)
+    out = {"finalProject": (n1, n0)}
+    cb = Scene.load(scene_path("cornell_box.xml"))
+    try:
+        r.set_option("tlas_min", 2)
+        both = {}
+        for cm in (64, 0):
+            r.set_option("cone_max_inst", cm)
+            both[cm] = check_soft_shadow_clear_view(r, cb, w, h, strict=strict, tol=tol, gate=gate)
+        # (the BVH walk gives up after a step budget and never proves more than the table walk does)
+        assert both[0][1] == both[64][1] and both[64][0] <= both[0][0] <= 1.1 * both[64][0], both
+        out["cornell"] = both
+    finally:
+        r.set_option("tlas_min", 24)
+        r.set_option("cone_max_inst", 64)
+    return out
 
 
 def check_reference_scene_fixtures(r, w, h, strict=None):
@@ -541,10 +573,21 @@ def check_reference_scene_fixtures(r, w, h, strict=None):
         assert scene.warnings == 0, f
         r.LoadScene(scene)
         orc = oracle_ffi.OracleScene(scene)
-        p = params(w, h, spp=1, jitter=0, bounces=0)
+        # deterministic frame (BASELINE config 1's settings: pixel centre, one shadow ray to every light's centre): ids bit-exact,
+        # every pixel's colour within 1e-4
+        p = params(w, h, spp=1, jitter=0, bounces=0, light_scale=0.0)
         g, c = r.Render(p), orc.render(p)
         assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face), f
         assert rel_colour_diff(g.radiance, c.radiance) <= 1e-4, f
+        # the same frame with the scene's sized lights (16..128 disc samples per group, sinf / cosf per sample): a sample that an
+        # ulp of the device's sincosf moves across a silhouette changes its pixel by 1 / 16 or 1 / 128 of a light's term
+        # (measured: 1 of 57 600 pixels of finalProject, its 64 glass spheres under two lights of size 4 and 8)
+        p = params(w, h, spp=1, jitter=0, bounces=0)
+        g, c = r.Render(p), orc.render(p)
+        assert np.array_equal(g.hit_node, c.hit_node) and np.array_equal(g.hit_face, c.hit_face), f
+        a, b = g.radiance[..., :3].astype(np.float64), c.radiance[..., :3].astype(np.float64)
+        within = ((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max(axis=-1) <= 1e-4)
+        assert within.mean() >= (1.0 if strict is not None else 0.9995), (f, within.mean())
         p = params(w // 2, h // 2, spp=2, jitter=1, bounces=2)
         p.shadow_min, p.shadow_max = 4, 8
         g, c = r.Render(p), orc.render(p)

@@ -102,6 +102,10 @@ def test_soft_shadow_clear_view_shortcut(emu):
     common_checks.check_soft_shadow_clear_view(emu, cb, 64, 48, strict=1e-4, shadow=(8, 8))
 
 
+def test_soft_shadow_proofs_through_the_instance_bvh(emu):
+    print(common_checks.check_soft_shadow_proofs_many_instances(emu, 64, 36, strict=1e-4))
+
+
 def test_device_bvh_build(emu, tmp_path):
     """Meshes without a tree get a linear BVH at rt_scene_commit (here: the same kernels under host emulation); a tree that
     comes with the mesh is handed back unchanged by rt_scene_mesh_bvh."""

@@ -76,6 +76,11 @@ def test_soft_shadow_clear_view_shortcut(gpu_renderer):
     cc.check_soft_shadow_clear_view(gpu_renderer, stress, 160, 90, tol=1e-5, min_saved=-1.0)
 
 
+def test_soft_shadow_proofs_through_the_instance_bvh(gpu_renderer):
+    """finalProject.xml (the scene the reference's main.cpp hard-codes; 70 instances) and a Cornell box forced both ways."""
+    print("proofs, many instances:", cc.check_soft_shadow_proofs_many_instances(gpu_renderer, 320, 180, tol=1e-5))
+
+
 def test_soft_shadow_proofs_full_size(gpu_renderer):
     """BASELINE configs 3 and 4 at their full frame sizes with their own integrator settings (C3: 4K, Monte-Carlo indirect, three
     bounces; C4's Cornell box at 1080p): the frame with the proofs equals the frame that traces every group — ids exactly,
