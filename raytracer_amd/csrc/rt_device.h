@@ -129,11 +129,13 @@ struct DScene {
   const int32_t* minst;  // indices (into inst) of the mesh instances, depth-first order
   const DMeshInst* minst_rec;  // ... and their records for the second-phase walk
   int32_t n_minst;
-  int32_t use_tlas;      // the scene has enough instances for the instance BVH below to pay (rt_scene_commit)
+  int32_t use_tlas;      // closest-hit rays walk the instance BVH below: the scene has enough instances for it to pay (rt_scene_commit)
   const float4* tlas;    // BVH over the instances' padded world boxes, 64-byte nodes as DScene::bvh
   const int32_t* tlas_idx;  // instance indices in leaf order
   uint32_t tlas_root;
-  uint32_t pad_;
+  int32_t shadow_tlas;   // ... and so do the shadow rays of the two-phase kernels.  Their waves are coherent (samples of a few shadow
+                         // groups), so the wave-uniform table walk with its 64-entries-at-a-time box cull and the proofs' masks
+                         // stays ahead of per-lane BVH walks up to a few hundred instances (finalProject.xml, 70: 3.1 -> G rays/s)
 };
 #define RT_H2 0
 #define RT_H3 128
@@ -328,11 +330,15 @@ RT_DEV uint32_t wave_or(uint32_t v) {
   for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m);
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+RT_DEV unsigned long long wave_or64(unsigned long long v) {
+  return ((unsigned long long)wave_or((uint32_t)(v >> 32)) << 32) | (unsigned long long)wave_or((uint32_t)v);
+}
 #else
 RT_DEV float wave_min(float v) { return v; }
 RT_DEV float wave_max(float v) { return v; }
 RT_DEV bool wave_any(bool v) { return v; }
 RT_DEV uint32_t wave_or(uint32_t v) { return v; }
+RT_DEV unsigned long long wave_or64(unsigned long long v) { return v; }
 #endif
 
 // ---- segmented queues ------------------------------------------------------------------------------
@@ -1064,12 +1070,12 @@ RT_DEV bool scene_closest(const DScene& S, V3 o, V3 dir, int hitSide, Hit& hit, 
 // Renderer::TraceShadowRay -> TraverseTreeShadow (RayTracer.cpp:346-371): any occluder with t < t_max.
 // SPLIT = true: first phase of the two-phase shadow kernels (see closest_instances).
 // `active`: this lane has a ray (the first-phase kernels call with every lane of the wave, see the wave-wide cull below).
-// MASKED: `inst_mask` names the instances (bit i: table entry i < 32; entries from 32 on always count) that can occlude this
+// MASKED: `inst_mask` names the instances (bit i: table entry i < 64; entries from 64 on always count) that can occlude this
 // lane's ray at all — what cone_clear could not exclude for the ray's soft-shadow group; the wave tests the union.
 template <bool CNT, bool SPLIT, bool MASKED = false>
 RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& cand_head, const CandSink& K, uint32_t* stk, uint32_t stride,
-                          Cnt<CNT>& cnt, bool active = true, uint32_t inst_mask = 0xFFFFFFFFu) {
-  const uint32_t wmask = MASKED ? wave_or(active ? inst_mask : 0u) : 0xFFFFFFFFu;
+                          Cnt<CNT>& cnt, bool active = true, unsigned long long inst_mask = ~0ull) {
+  const unsigned long long wmask = MASKED ? wave_or64(active ? inst_mask : 0ull) : ~0ull;
   V3 winv = v3(0, 0, 0);
   if (S.n_minst > 0) winv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // (only the mesh world boxes need it)
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
@@ -1088,7 +1094,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
   V3 smin = v3(-RT_BIG, -RT_BIG, -RT_BIG), smax = v3(RT_BIG, RT_BIG, RT_BIG);
   // (with a mask that covers the whole table the mask is the cull: it is per group and exact about shapes, the box is
   // per wave and about boxes)
-  const bool box_cull = SPLIT && !(MASKED && S.n_inst <= 32 && wmask != 0xFFFFFFFFu);   // [wave-uniform]
+  const bool box_cull = SPLIT && !(MASKED && S.n_inst <= 64 && wmask != ~0ull);   // [wave-uniform]
   if (box_cull) {
     const float tseg = t_max < 1e30f ? t_max : 1e30f;
     const V3 e = o + dir * tseg;
@@ -1113,7 +1119,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
           const DInstance& J = S.inst[li];
           keep = !(smin.x > J.wmax[0] || smax.x < J.wmin[0] || smin.y > J.wmax[1] || smax.y < J.wmin[1] || smin.z > J.wmax[2] ||
                    smax.z < J.wmin[2]);
-          if (MASKED && li < 32) keep = keep && ((wmask >> li) & 1u);
+          if (MASKED && li < 64) keep = keep && ((wmask >> li) & 1ull);
         }
         live = __ballot(keep);
       }
@@ -1127,7 +1133,7 @@ RT_DEV bool any_instances(const DScene& S, V3 o, V3 dir, float t_max, uint32_t& 
     if (SPLIT && (smin.x > I->wmax[0] || smax.x < I->wmin[0] || smin.y > I->wmax[1] || smax.y < I->wmin[1] || smin.z > I->wmax[2] ||
                   smax.z < I->wmin[2]))
       continue;
-    if (MASKED && i < 32 && !((wmask >> i) & 1u)) continue;
+    if (MASKED && i < 64 && !((wmask >> i) & 1ull)) continue;
 #endif
     int prim = I->prim;
     V3 p, d;
@@ -1304,14 +1310,14 @@ RT_DEV bool cone_free_of(const Cone& K, int prim, V3 p, V3 d, float grow, bool t
   }
   return beyond || leaving;
 }
-// `may_occlude`: bit i = table entry i (< 32) could not be excluded for this group's rays (any_instances<.., MASKED>).
-RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_t& may_occlude) {
+// `may_occlude`: bit i = table entry i (< 64) could not be excluded for this group's rays (any_instances<.., MASKED>).
+RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, unsigned long long& may_occlude) {
   RT_UTYPE(DInstance)* inst = RT_UNIFORM_PTR(DInstance, S.inst);
   RT_UTYPE(float)* xf = RT_UNIFORM_PTR(float, S.xf);
   const Cone K = cone_of(P, C, R, active);
   const bool sized = K.sized;
   bool clear = sized, umbra = false;
-  may_occlude = sized ? 0u : 0xFFFFFFFFu;
+  may_occlude = sized ? 0ull : ~0ull;
   ParentRay pr;
   pr.key = -2; pr.p = P; pr.d = K.a;
   for (int i = 0; i < S.n_inst; i++) {
@@ -1320,13 +1326,13 @@ RT_DEV int cone_clear(const DScene& S, V3 P, V3 C, float R, bool active, uint32_
     const int prim = I->prim;
     if (!wave_any(touch)) continue;   // [wave-uniform]
     if (prim == 3) {
-      if (touch) { clear = false; if (i < 32) may_occlude |= 1u << i; }
+      if (touch) { clear = false; if (i < 64) may_occlude |= 1ull << i; }
       continue;
     }
     V3 p, d;
     ray_to_instance(I, xf, P, K.a, pr, p, d);
     const bool free_of = cone_free_of(K, prim, p, d, I->stretch, touch, umbra);
-    if (touch && !free_of) { clear = false; if (i < 32) may_occlude |= 1u << i; }
+    if (touch && !free_of) { clear = false; if (i < 64) may_occlude |= 1ull << i; }
   }
   return umbra ? RT_CONE_UMBRA : (clear ? RT_CONE_CLEAR : RT_CONE_TRACE);
 }

@@ -925,12 +925,12 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
         if (gi != RT_NONE) {
           GS.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
           GS.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
-          GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), 0.0f);
+          GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));   // (.w: instances 32..63 that may occlude)
           V3 toSP = normalized(sp.P - v3(L->position[0], L->position[1], L->position[2]));  // lights.cpp:21-22, 31-32
           V3 tangent, bitangent;
           orthonormals(toSP, tangent, bitangent);
           GS.g3[gi] = make_float4(tangent.x, tangent.y, tangent.z, L->size * P.light_size_scale);
-          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, __uint_as_float(0xFFFFFFFFu));   // (.w: instances that may occlude, k_shadow_soft_clear)
+          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, __uint_as_float(0xFFFFFFFFu));   // (.w: instances 0..31 that may occlude, k_shadow_soft_clear)
         }
       } else {
         uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
@@ -1052,7 +1052,8 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
   const uint32_t* counts = list ? list_counts : G.counts;
   const unsigned long long nj_magic = ((1ull << 40) + nj - 1u) / nj;   // ceil(2^40 / nj): e / nj == (e * magic) >> 40 for e < 2^32
   RT_SEG_BEGIN(counts, G.nseg, G.segcap, nj)
-    uint32_t g = RT_NONE, j = 0, inst_mask = 0xFFFFFFFFu;
+    uint32_t g = RT_NONE, j = 0;
+    unsigned long long inst_mask = ~0ull;
     uint32_t head = RT_NONE;
     bool lit = false;
     V3 Pp = v3(0, 0, 0), d = v3(1, 0, 0);
@@ -1065,9 +1066,9 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
       uint32_t e = seg_base_ + q;
       g = list ? list[e] : e;
       j = j0 + (e32 - q * nj);
-      const float4 g4 = G.g4[g];
-      inst_mask = __float_as_uint(g4.w);
-      soft_shadow_ray(S, G.g0[g], G.g2[g], G.g3[g], g4, j, Pp, d, dist);
+      const float4 g4 = G.g4[g], g2 = G.g2[g];
+      inst_mask = ((unsigned long long)__float_as_uint(g2.w) << 32) | (unsigned long long)__float_as_uint(g4.w);
+      soft_shadow_ray(S, G.g0[g], g2, G.g3[g], g4, j, Pp, d, dist);
       rays++;
     }
     const CandSink K = cand_sink(MQ, sw_.s % MQ.nseg, F.overflow);
@@ -1190,7 +1191,7 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
       C = v3(L.position[0], L.position[1], L.position[2]);
       R = G.g3[g].w;
     }
-    uint32_t may_occlude = 0xFFFFFFFFu;
+    unsigned long long may_occlude = ~0ull;
     int view;
     if (TLAS) view = seg_valid ? cone_clear_tlas(S, Pp, C, R, true, stk, stride) : RT_CONE_TRACE;   // (per lane: the instance BVH)
     else view = cone_clear(S, Pp, C, R, seg_valid, may_occlude);                                    // (every lane: wave-uniform table walk)
@@ -1202,7 +1203,8 @@ RT_KERNEL(k_shadow_soft_clear, DScene S, PassP P, FrameBufs F, GroupQ G, uint32_
     uint32_t li = seg_push(seg_valid && view == RT_CONE_TRACE, n1, sw_.s, G.segcap, F.overflow);
     if (li != RT_NONE) {
       list1[li] = g;
-      ((uint32_t*)&G.g4[g])[3] = may_occlude;   // the rays of this group are tested against these instances only (k_shadow_soft)
+      ((uint32_t*)&G.g4[g])[3] = (uint32_t)may_occlude;   // the rays of this group are tested against these instances only (k_shadow_soft)
+      ((uint32_t*)&G.g2[g])[3] = (uint32_t)(may_occlude >> 32);
     }
   RT_SEG_END
   if (CNT && proven) rt_atomic_add_u64(&F.counters->rays_shadow_proven, proven);

@@ -61,8 +61,11 @@
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 8   // streaming kernels: measured 4 -> 8 blocks per CU: k_shade 5.8 -> 4.8 ms per bench step
 #endif
+#ifndef RT_SHADOW_TLAS_MIN
+#define RT_SHADOW_TLAS_MIN 256   // instances from which the two-phase shadow kernels walk the instance BVH, too (below it: the table walk)
+#endif
 #ifndef RT_CONE_MAX_INST
-#define RT_CONE_MAX_INST 64    // soft-shadow proofs (cone_clear) walk the instance table linearly: ~25 instructions per entry and group,
+#define RT_CONE_MAX_INST 256   // soft-shadow proofs (cone_clear) walk the instance table linearly: ~25 instructions per entry and group,
                                // against the 16 rays through the instance BVH (~300 each) a proof may save
 #endif
 #ifndef RT_TLAS_MIN
@@ -110,7 +113,8 @@ alignas(256) static unsigned char scratch[RT_NOALLOC_BYTES];
 // Developer knobs (tests force both sides of a threshold with them).  Read from the environment ONCE, when the context is
 // created, and settable per context through rt_set_option; nothing on the render path calls getenv.
 struct Options {
-  double tlas_min = RT_TLAS_MIN;   // "tlas_min"     RT_TLAS_MIN      instances from which the instance BVH is used
+  double tlas_min = RT_TLAS_MIN;   // "tlas_min"     RT_TLAS_MIN      instances from which the instance BVH is used (closest-hit rays)
+  double shadow_tlas_min = RT_SHADOW_TLAS_MIN;   // "shadow_tlas_min"  ... and from which the two-phase shadow kernels use it (never below tlas_min)
   double gather_hints = 1;         // "gather_hints" RT_GATHER_HINTS  0: every photon lookup from scratch
   double frame_gb = 0;             // "frame_gb"     RT_FRAME_GB      stage-queue memory of one pass (0: frame_mem_mb / 32 GB)
   double fan_scale = 1;            // "fan_scale"    RT_TEST_FAN_SCALE  scales the measured queue sizing (tests: forces overflow)
@@ -628,6 +632,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "timing") ctx->opt.timing = value;
   else if (n == "soft_clear") ctx->opt.soft_clear = value;
   else if (n == "cone_max_inst") ctx->opt.cone_max_inst = value;
+  else if (n == "shadow_tlas_min") ctx->opt.shadow_tlas_min = value;   // takes effect at the next rt_scene_commit
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
   return RT_OK;
 }
@@ -931,6 +936,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   // instance BVH: pays once the wave-uniform table loop is longer than a short divergent walk; the nested mesh walk of
   // the one-phase callers (rt_trace_closest / rt_trace_any, photons) shares the per-lane stack with it
   D.use_tlas = 0;
+  D.shadow_tlas = 0;
   int tlas_depth = 0;
   const size_t tlas_min = (size_t)std::max(0.0, ctx->opt.tlas_min);   // (developer knob: tests force both paths)
   if (inst.size() >= tlas_min && inst.size() >= 2) {
@@ -943,6 +949,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       if ((rc = upload(ctx, ctx->scene_mem, tb.order, &D.tlas_idx))) return rc;
       D.tlas_root = root;
       D.use_tlas = 1;
+      D.shadow_tlas = inst.size() >= (size_t)std::max(0.0, ctx->opt.shadow_tlas_min) ? 1 : 0;
       tlas_depth = tb.max_depth;
     }
   }
@@ -1754,7 +1761,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       Timer t(ctx, RT_K_SHADOW);
       MeshQ MH = meshq(ctx->MH, lvl, CNT_MH, CUR_MH);
       uint64_t gh_ub = std::min<uint64_t>(ubn * 4, (uint64_t)GH.segcap * GH.nseg);
-      if (ctx->ds.use_tlas) LAUNCH_T((k_shadow_hard<CNT, true>), gh_ub, ctx->ds, P, F, GH, MH);
+      if (ctx->ds.shadow_tlas) LAUNCH_T((k_shadow_hard<CNT, true>), gh_ub, ctx->ds, P, F, GH, MH);
       else LAUNCH_P1((k_shadow_hard<CNT, false>), gh_ub, ctx->ds, P, F, GH, MH);
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
       if (meshes) {
@@ -1772,13 +1779,14 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       // RT_CONE_MAX_INST instances, the instance BVH with the cone in place of a ray)
       const bool cone_table = ctx->ds.n_inst <= (int)ctx->opt.cone_max_inst;
       const bool clear_first = ctx->opt.soft_clear != 0 && (cone_table || ctx->ds.use_tlas);
+      const bool soft_tlas = ctx->ds.shadow_tlas != 0;
       uint32_t* n1 = ctx->d_counts + cnt_at(lvl, CNT_N1);
       const uint32_t* list1 = clear_first ? ctx->d_list1 : nullptr;
       {
         Timer t(ctx, RT_K_SHADOW);
         if (clear_first && cone_table) LAUNCH_P1((k_shadow_soft_clear<CNT, false>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
         else if (clear_first) LAUNCH_T((k_shadow_soft_clear<CNT, true>), gs_ub, ctx->ds, P, F, GS, ctx->d_list1, n1);
-        if (ctx->ds.use_tlas)
+        if (soft_tlas)
           LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)P.shadow_min, ctx->ds, P, F, GS, list1, (const uint32_t*)(list1 ? n1 : nullptr), 0u,
                    (uint32_t)P.shadow_min, MS1);
         else
@@ -1809,7 +1817,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
           }
           {
             Timer t(ctx, RT_K_SHADOW);
-            if (ctx->ds.use_tlas)
+            if (soft_tlas)
               LAUNCH_T((k_shadow_soft<CNT, true>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2, j0, nr, MS2);
             else
               LAUNCH_P1((k_shadow_soft<CNT, false>), gs_ub * (uint64_t)nr, ctx->ds, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2, j0, nr, MS2);

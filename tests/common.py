@@ -521,7 +521,7 @@ def check_soft_shadow_clear_view_random(r, seeds, w, h, strict=None, tol=2e-6):
             tot1, tot0 = tot1 + n1, tot0 + n0
     finally:
         r.set_option("tlas_min", 24)
-        r.set_option("cone_max_inst", 64)
+        r.set_option("cone_max_inst", 256)
     assert tot1 < 0.9 * tot0
     return tot1, tot0
 
@@ -537,21 +537,30 @@ def check_soft_shadow_proofs_many_instances(r, w, h, strict=None, tol=2e-6):
     fp = Scene.load(os.path.join(GOLDEN, "scenes", "ref_finalProject.xml"), asset_dir=ROOT)
     assert fp.desc.n_nodes > 70
     gate = dict(frac=0.999, psnr=60.0, mean=1e-5)
-    n1, n0 = check_soft_shadow_clear_view(r, fp, w, h, strict=strict, tol=tol, min_saved=0.3, gate=gate, bounces=2)
-    out = {"finalProject": (n1, n0)}
-    cb = Scene.load(scene_path("cornell_box.xml"))
+    out = {}
     try:
+        # 70 instances: by default the proofs and the shadow rays walk the instance table (64-bit masks of the instances a group's
+        # rays still have to be tested against); forced: both through the instance BVH
+        for name, cone_max, shadow_min in (("table", 256, 256), ("bvh", 0, 2)):
+            r.set_option("cone_max_inst", cone_max)
+            r.set_option("shadow_tlas_min", shadow_min)
+            out["finalProject " + name] = check_soft_shadow_clear_view(r, fp, w, h, strict=strict, tol=tol, min_saved=0.3, gate=gate, bounces=2)
+        a, b = out["finalProject table"], out["finalProject bvh"]
+        assert a[1] == b[1] and a[0] <= b[0] <= 1.1 * a[0], out
+        r.set_option("shadow_tlas_min", 256)
+        cb = Scene.load(scene_path("cornell_box.xml"))
         r.set_option("tlas_min", 2)
         both = {}
-        for cm in (64, 0):
+        for cm in (256, 0):
             r.set_option("cone_max_inst", cm)
             both[cm] = check_soft_shadow_clear_view(r, cb, w, h, strict=strict, tol=tol, gate=gate)
         # (the BVH walk gives up after a step budget and never proves more than the table walk does)
-        assert both[0][1] == both[64][1] and both[64][0] <= both[0][0] <= 1.1 * both[64][0], both
+        assert both[0][1] == both[256][1] and both[256][0] <= both[0][0] <= 1.1 * both[256][0], both
         out["cornell"] = both
     finally:
         r.set_option("tlas_min", 24)
-        r.set_option("cone_max_inst", 64)
+        r.set_option("cone_max_inst", 256)
+        r.set_option("shadow_tlas_min", 256)
     return out
 
 
