@@ -423,24 +423,42 @@ def run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief):
         sh_inst = cnt["inst_tests"] - cnt["closest_inst_tests"]          # shadow-ray instance tests, both phases
         sh_nodes = cnt["node_visits"] - cnt["closest_node_visits"]
         sh_tris = cnt["tri_tests"] - cnt["closest_tri_tests"]
+        # Which kernels ran: scenes whose closest-hit rays walk the instance table (fewer than RT_TLAS_MIN = 24 instances) take
+        # the FUSED first phase — k_raygen_shade / k_trace_shade trace a ray through the instance table and shade it right there
+        # unless it reaches a mesh box; only those rays go through a queue, k_trace_mesh and k_shade.  Scenes with an instance
+        # BVH keep k_raygen_trace / k_trace_closest and shade everything in k_shade.
+        n_inst = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.nodes[i].prim_kind != 0)
+        fused = n_inst < int(float(os.environ.get("RT_TLAS_MIN", "24"))) and os.environ.get("RT_FUSE", "1") != "0"
+        all_rays = max(tc_rays, 1)
+        mesh_frac = min(1.0, cnt["mesh_items"] / all_rays) if fused else 1.0    # share of the shade points k_shade handles
+        # 84 B per shade point in (k_shade only: the fused kernels shade from registers), 64 B per child ray, ~48 B per shadow
+        # group (32 hard / 80 soft; groups <= shade points x lights), 16 B per texture lookup
+        shade_out_bytes = 64.0 * cnt["rays_secondary"] + 48.0 * min(cnt["rays_shadow"], cnt["shades"] * scene.desc.n_lights) + 16.0 * cnt["tex_evals"]
+        shade_flops = (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"]
+        first_flops = (36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
+                       / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0))
+        if fused:
+            first = ("k_raygen_shade+k_trace_shade",
+                     ({"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
+                      # 12 B per path (radiance slot cleared), 64 B per secondary ray read, 80 B per ray handed to the mesh phase
+                      # (64 B entry + 16 B work item), and this share of the shade points' outputs
+                      12.0 * cnt["paths"] + 64.0 * cnt["rays_secondary"] + 80.0 * cnt["mesh_items"] + (1.0 - mesh_frac) * shade_out_bytes,
+                      first_flops + (1.0 - mesh_frac) * shade_flops, "k_raygen_shade<false"))
+        else:
+            first = ("k_raygen_trace+k_trace_closest",
+                     ({"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
+                      # camera rays: 80 B written per path, generated and traced in registers; secondary rays 48 B; the instance
+                      # BVH's boxes count when it is used
+                      80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"] + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
+                      first_flops, "k_raygen_trace<false"))
         kern = {
-            # first phase of the closest-hit queries: k_raygen_trace (camera rays: 80 B written per path, generated and
-            # traced in registers) + k_trace_closest (secondary rays); the instance BVH's boxes count when it is used
-            "k_raygen_trace+k_trace_closest": (
-                {"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
-                80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"]
-                + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
-                36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
-                / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
-                "k_raygen_trace<false"),
+            first[0]: first[1],
             "k_trace_mesh": (prof["trace_mesh"],
                              48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"],
                              36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"],
                              "k_trace_mesh<false"),
-            # 84 B per shade point in, 64 B per child ray, ~48 B per shadow group (32 hard / 80 soft; groups <= shade points x lights)
-            "k_shade": (prof["shade"], 84.0 * cnt["shades"] + 64.0 * cnt["rays_secondary"]
-                        + 48.0 * min(cnt["rays_shadow"], cnt["shades"] * scene.desc.n_lights) + 16.0 * cnt["tex_evals"],
-                        (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"], "k_shade<false"),
+            "k_shade": (prof["shade"], 84.0 * (cnt["mesh_items"] if fused else cnt["shades"]) + mesh_frac * shade_out_bytes,
+                        mesh_frac * shade_flops, "k_shade<false"),
             # shadow rays, first phase (k_shadow_hard / k_shadow_soft): every instance test is charged here
             "k_shadow": (prof["shadow"], 48.0 * cnt["rays_shadow"],
                          36.0 * sh_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * cnt["rays_shadow"]
@@ -518,6 +536,7 @@ def run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief):
                        "partition": "sample-range split; RCCL sum-reduce of (sum rgb, n) per frame, overlapped with the next frame's rendering" if world > 1 else "single GPU",
                        # what the exchange actually ran over (N > 1): the process group's backend and the ranks it saw
                        "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "first_phase_fused_with_shading": fused,
                        "kernel_ms_per_step": kernel_ms, "counters_per_step": cnt},
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": d["hbm_traffic_bytes_per_launch"],

@@ -1247,6 +1247,12 @@ RT_DEV bool cone_touches_box(const Cone& K, float lx, float ly, float lz, float 
 // far a unit world length reaches there (chain_stretch, computed at commit).  Returns true when no ray of the cone can be
 // occluded by the instance; sets `umbra` when every ray is.
 RT_DEV bool cone_free_of(const Cone& K, int prim, V3 p, V3 d, float grow, bool touch, bool& umbra) {
+  // The one routine of the path compiled WITH floating-point contraction: every comparison below carries a margin of 1e-3 or
+  // more against the per-ray tests it bounds, so an fma's missing rounding step cannot change a proof, and the kernel that runs
+  // it is bound by VALU issue (98 % of the slots).  Everything that decides a hit keeps the reference's operation order.
+#ifndef RT_EMU
+#pragma clang fp contract(fast)
+#endif
   const float len = K.len, R = K.R, s_max = K.s_max;
   const float mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
   const float slack = 1e-5f * (1.0f + mag);

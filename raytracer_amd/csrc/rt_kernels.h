@@ -659,304 +659,396 @@ RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs,
 
 // Every lane of a wave runs every queue-append site of an iteration (predicated), so the per-wave chunk state of
 // wave_push stays uniform; see WavePush.
-// MC / PH: the indirect-diffuse sampler / the photon term can be on in this pass (compiled out otherwise: the kernel is
-// held back by its registers, and a frame uses one combination throughout).
+// MC / PH: the indirect-diffuse sampler / the photon term can be on in this pass (compiled out otherwise: the kernels are
+// held back by their registers, and a frame uses one combination throughout).
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4   // measured on the C2 bench: 2 -> 7.37 ms, 3 -> 6.52 ms, 4 -> 6.26 ms per step
 #endif
-#ifdef RT_SHADE_STATS   // developer build: wave cycles per region of k_shade
-__device__ unsigned long long g_shade_stats[16];
-#define SPHASE(ph) do { long long tn_ = clock64(); if (rt_lane() == 0) ss[sphase] += (unsigned long long)(tn_ - stprev); stprev = tn_; sphase = (ph); } while (0)
-#else
-#define SPHASE(ph) do { } while (0)
-#endif
+// One shade point: SendRay's dispatch on the closest hit `B` of the ray (q0, q1, q2, ids m) — miss / light / surface —, the hit's
+// attributes, MtlBlinn::Shade's unshadowed terms, and the appends of its children (-> QN), shadow groups (-> GH / GS) and photon
+// lookup (-> GQ), all into segment `oseg`.  Called by k_shade for the rays that went through a mesh BVH, and by the first-phase
+// trace kernels themselves (k_raygen_shade, k_trace_shade) for the rays they finish: those never travel through a queue
+// between being traced and being shaded.  A re-shade entry (lights.cpp:172-183) brings its hit record in Q.h0..h2[idx]
+// instead of B.  EVERY lane of the wave must call (`valid`: this lane has a shade point).
+template <bool CNT, bool MC, bool PH>
+RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, uint32_t idx, const RayQ& QN, const GroupQ& GH,
+                        const GroupQ& GS, const GatherQ& GQ, uint32_t oseg, bool valid, uint4 m, float4 q0, float4 q1, float4 q2, const Best& B,
+                        Cnt<CNT>& cnt, uint32_t& n_shades) {
+  RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);
+  uint32_t slot = m.x, pixel = m.y;
+  uint32_t nid = m.w & 0xFFFu, bounce = (m.w >> 12) & 7u;
+  bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
+
+  bool surface = false;
+  const bool aov = bounce == 0 && F.aov_depth && (int)m.z == P.aov_sample && valid;
+  V3 aov_n = v3(0, 0, 0), aov_a = v3(1, 1, 1);
+  float aov_z = RT_BIG;
+  ShadePt sp;
+  sp.P = sp.N = sp.V = sp.uvw = v3(0, 0, 0);
+  sp.front = true; sp.pixel = pixel; sp.nid = nid; sp.sample = (int)m.z;
+  V3 w = v3(0, 0, 0), mabs = v3(0, 0, 0), cKd = v3(0, 0, 0), cKs = v3(0, 0, 0), kd = v3(0, 0, 0);
+  float alpha = 0.0f, zs = 0.0f;
+  float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
+  ChildRay c_refr, c_refl, c_mc;
+  bool p_refr = false, p_refl = false, p_mc = false, p_gather = false, refl_below = false;
+  c_refr.o = c_refr.d = c_refr.w = c_refl.o = c_refl.d = c_refl.w = c_mc.o = c_mc.d = c_mc.w = v3(0, 0, 0);
+  c_refr.meta = c_refl.meta = c_mc.meta = 0;
+  V3 wk = v3(0, 0, 0);
+
+  if (valid) {
+    float4 h0;
+    if (reshade) {  // the hit record k_shade wrote for this entry (lights.cpp:172-183)
+      h0 = Q.h0[idx];
+      h1 = Q.h1[idx];
+      h2 = Q.h2[idx];
+    } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
+      Hit h;
+      finalize_hit_from(S, S.sinst, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
+      h0 = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+      h1 = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
+      h2 = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float((h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8)));
+      if (bounce == 0 && F.hit_node && (int)m.z == P.aov_sample) {
+        F.hit_node[pixel] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.sinst[h.inst].node : -1);
+        F.hit_face[pixel] = h.light >= 0 ? -1 : h.face;
+      }
+    }
+    w = v3(q0.w, q1.w, q2.w);
+    V3 pabs = v3(q2.x, q2.y, q2.z);
+    V3 rdir = v3(q1.x, q1.y, q1.z);
+    int inst = (int)__float_as_uint(h1.w);
+    uint32_t flags = __float_as_uint(h2.w);
+    int light = (int)((flags >> 8) & 0xFFFFu) - 1;
+    bool front = flags & 1u;
+    float z = h0.w;
+    if (inst < 0 && light < 0) {  // miss
+      if (bounce == 0) {          // RayTracer.cpp:253-258
+        float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
+        float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
+        V3 bg = eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt);
+        aov_a = bg;
+        add_radiance(F, slot, w * bg);
+      } else {                    // lights.cpp:204-208, dist = BIGFLOAT
+        V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
+        add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
+      }
+    } else if (light >= 0) {
+      aov_z = z * length(rdir);
+      if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
+        const DLight& L = S.lights[light];
+        V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
+        add_radiance(F, slot, w * c);
+      } else {                    // lights.cpp:199-202
+        add_radiance(F, slot, w * absorb(v3(1, 1, 1), pabs, z));
+      }
+    } else {
+      // SamplerInfo::SetHit, renderer.h:142-150
+      zs = z * length(rdir);
+      sp.N = normalized(v3(h1.x, h1.y, h1.z));
+      V3 nd = normalized(rdir);
+      sp.V = -nd;
+      sp.P = v3(h0.x, h0.y, h0.z);
+      sp.uvw = v3(h2.x, h2.y, h2.z);
+      sp.front = front;
+      if (bounce > 0) {  // lights.cpp:194 and materials.cpp:255-259 / 277-281, applied to this subtree's weight
+        float dist = reshade ? 0.0f : (front ? zs : 0.0f);
+        w = absorb(w, pabs, dist);
+      }
+      n_shades++;
+      aov_z = zs; aov_n = sp.N;
+      const DMaterial& M = S.sinst[inst].mtl;
+      if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
+        add_radiance(F, slot, w);
+      } else {
+        surface = true;
+        // materials.cpp:231-236
+        // (one copy of the texture code in a loop that is not unrolled, results routed by selects, was measured: the
+        // kernel shrinks by a third and runs 5 % SLOWER on C2 — the six inlined copies stay)
+        V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
+        V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
+        kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
+        V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
+        alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
+        V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
+        aov_a = kd;
+        float diffScalar = (float)(1 / RT_PI_D);
+        float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
+        cKd = kd * diffScalar;
+        cKs = ks * specScalar;
+        V3 fullReflection = reflection;
+        mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
+        bool can_bounce = (int)bounce < P.max_bounces;
+        float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+        bool have_r0 = false, have_r1 = false;
+        float mior = M.ior, mgloss = M.glossiness.v;
+        if (mior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
+          float iorRatio = (1.0f - mior) / (1.0f + mior);
+          V3 fresnel = refraction * (iorRatio * iorRatio);
+          fullReflection = fullReflection + fresnel;
+          V3 wc = w * (refraction * (v3(1, 1, 1) - fullReflection));
+          if (nonzero(wc)) {
+            shade_draws(P, sp, 0, r0); have_r0 = true;
+            shade_draws(P, sp, 1, r1); have_r1 = true;
+            refract_ray(S, sp, mior, mgloss, r0, r1, c_refr.o, c_refr.d);
+            c_refr.w = wc;
+            c_refr.meta = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
+            p_refr = true;
+          }
+        }
+        if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
+          V3 wc = w * reflection;
+          if (nonzero(wc)) {
+            if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
+            c_refl.d = reflect_dir(S, sp, mgloss, r0[2], r0[3]);
+            c_refl.o = sp.P;
+            c_refl.w = wc;
+            refl_below = dot(c_refl.d, sp.N) < 0;  // lights.cpp:174: re-shade the same point with the new view direction
+            c_refl.meta = RT_META(nid * 4 + 2, bounce + 1, 1, refl_below ? 1 : 0);
+            p_refl = true;
+          }
+        }
+        V3 local = emission;
+        if (MC && P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
+          V3 wc = w * kd;
+          if (nonzero(wc)) {
+            if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
+            int hi = (sp.sample * P.mc_samples) % 1000;
+            float u1 = wrap01(S.halton[RT_HPHI + hi] + r1[2]);
+            float u2 = wrap01(S.halton[RT_HTHETA + hi] + r1[3]);
+            float r = sqrtf(u1);
+            float phi = two_pi_times(u2);
+            float sn, cs;
+            sincosf(phi, &sn, &cs);
+            float x = r * cs, y = r * sn, zz = sqrtf(1.0f - u1);
+            V3 t, b;
+            orthonormals(sp.N, t, b);
+            c_mc.d = normalized((x * t) + (y * b) + (zz * sp.N));
+            c_mc.o = sp.P;
+            c_mc.w = wc;
+            c_mc.meta = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
+            p_mc = true;
+          }
+        } else if (PH && P.photons) {  // materials.cpp:315-322
+          wk = w * ((float)(1.0f / RT_PI_D) * kd);
+          p_gather = nonzero(wk);
+        }
+        add_radiance(F, slot, w * local);
+      }
+    }
+  }
+  if (aov) {
+    F.aov_depth[pixel] = aov_z;
+    F.aov_normal[3 * (size_t)pixel] = aov_n.x; F.aov_normal[3 * (size_t)pixel + 1] = aov_n.y; F.aov_normal[3 * (size_t)pixel + 2] = aov_n.z;
+    F.aov_albedo[3 * (size_t)pixel] = aov_a.x; F.aov_albedo[3 * (size_t)pixel + 1] = aov_a.y; F.aov_albedo[3 * (size_t)pixel + 2] = aov_a.z;
+  }
+  // ---- queue appends (all lanes of the wave pass through here); the three kinds of children share one atomic
+  {
+    uint32_t cpos[3];
+    seg_push3(p_refr, p_refl, MC && p_mc, QN.counts, oseg, QN.segcap, F.overflow, cpos);
+    if (cpos[0] != RT_NONE) write_child(QN, cpos[0], c_refr, mabs, slot, pixel, m.z);
+    if (cpos[1] != RT_NONE) {
+      write_child(QN, cpos[1], c_refl, mabs, slot, pixel, m.z);
+      if (refl_below) {
+        QN.h0[cpos[1]] = make_float4(sp.P.x, sp.P.y, sp.P.z, zs);
+        QN.h1[cpos[1]] = make_float4(sp.N.x, sp.N.y, sp.N.z, h1.w);
+        QN.h2[cpos[1]] = h2;
+      }
+    }
+    if (MC && cpos[2] != RT_NONE) write_child(QN, cpos[2], c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
+  }
+  // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
+  for (int li = 0; li < S.n_lights; li++) {
+    RT_UTYPE(DLight)* L = lights + li;
+    int kind = L->kind;
+    if (kind == 1) continue;  // ambient is accumulated and never added  [uniform branch]
+    bool soft = false, lit = false;
+    V3 contrib = v3(0, 0, 0);
+    float rx = 0, ry = 0;
+    if (kind == 3) soft = (L->size * P.light_size_scale) != 0.0f;
+    if (surface) {
+      V3 lightDir, inten = v3(L->intensity[0], L->intensity[1], L->intensity[2]);
+      if (kind == 2) {  // lights.h:45
+        lightDir = -v3(L->direction[0], L->direction[1], L->direction[2]);
+      } else {          // lights.cpp:62-71
+        V3 dl = v3(L->position[0], L->position[1], L->position[2]) - sp.P;
+        float dist = length(dl);
+        lightDir = normalized(dl);
+        if (L->attenuation != 0.0f) inten = inten / (dist * dist);
+      }
+      V3 h = normalized(lightDir + sp.V);
+      float cosphi = fmaxf(dot(sp.N, h), 0.0f);
+      float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
+      // (0 * powf(..) is +0 for every finite power of a cosine in [0, 1]: a wave of purely diffuse points skips powf)
+      const float spec = nonzero(cKs) ? powf(cosphi, alpha) : 0.0f;
+      contrib = w * (inten * ((costheta * cKd) + (cKs * spec)));
+      lit = nonzero(contrib);
+      if (lit && soft) {
+        float rl[4];
+        shade_draws(P, sp, 2 + (uint32_t)li, rl);
+        rx = rl[0]; ry = rl[1];
+      }
+    }
+    if (soft) {
+      uint32_t gi = seg_push(lit, GS.counts, oseg, GS.segcap, F.overflow);
+      if (gi != RT_NONE) {
+        GS.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
+        GS.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+        GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));   // (.w: instances 32..63 that may occlude)
+        V3 toSP = normalized(sp.P - v3(L->position[0], L->position[1], L->position[2]));  // lights.cpp:21-22, 31-32
+        V3 tangent, bitangent;
+        orthonormals(toSP, tangent, bitangent);
+        GS.g3[gi] = make_float4(tangent.x, tangent.y, tangent.z, L->size * P.light_size_scale);
+        GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, __uint_as_float(0xFFFFFFFFu));   // (.w: instances 0..31 that may occlude, k_shadow_soft_clear)
+      }
+    } else {
+      uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
+      if (gi != RT_NONE) {
+        GH.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
+        GH.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+      }
+    }
+  }
+  if (PH && P.photons) {
+    uint32_t gi = seg_push(p_gather, GQ.counts, oseg, GQ.segcap, F.overflow);
+    if (gi != RT_NONE) {
+      GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));
+      GQ.b[gi] = make_float4(sp.N.x, sp.N.y, sp.N.z, __uint_as_float(secondary ? 1u : 0u));
+      GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
+    }
+  }
+}
+
 template <bool CNT, bool MC, bool PH>
 RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
-  RT_UTYPE(DLight)* lights = RT_UNIFORM_PTR(DLight, S.lights);
-#ifdef RT_SHADE_STATS
-  unsigned long long ss[16] = {0};
-  long long stprev = clock64(); int sphase = 0;
-#endif
   RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
-    SPHASE(1);
     const uint32_t oseg = sw_.s % QN.nseg;  // children and shadow work stay in the parent's segment
     uint32_t idx = seg_base_ + (uint32_t)seg_e;
-    bool valid = seg_valid;
     // the whole entry is requested at once (ids, ray, weights, raw hit): one memory round trip per iteration instead of
     // ids first, then whatever they select
     uint4 m;
     m.x = m.y = m.z = 0; m.w = 0;
     float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, raw0 = q0;
     uint32_t raw_face = 0;
-    if (valid) {
+    if (seg_valid) {
       m = Q.q3[idx];
       q0 = Q.q0[idx]; q1 = Q.q1[idx]; q2 = Q.q2[idx];
-      raw0 = Q.r0[idx]; raw_face = Q.rf[idx];   // (stale for a re-shade entry, which brings its own hit record)
+      raw0 = Q.r0[idx]; raw_face = Q.rf[idx];
     }
-    uint32_t slot = m.x, pixel = m.y;
-    uint32_t nid = m.w & 0xFFFu, bounce = (m.w >> 12) & 7u;
-    bool secondary = (m.w >> 15) & 1u, reshade = (m.w >> 16) & 1u;
-
-    bool surface = false;
-    const bool aov = bounce == 0 && F.aov_depth && (int)m.z == P.aov_sample && valid;
-    V3 aov_n = v3(0, 0, 0), aov_a = v3(1, 1, 1);
-    float aov_z = RT_BIG;
-    ShadePt sp;
-    sp.P = sp.N = sp.V = sp.uvw = v3(0, 0, 0);
-    sp.front = true; sp.pixel = pixel; sp.nid = nid; sp.sample = (int)m.z;
-    V3 w = v3(0, 0, 0), mabs = v3(0, 0, 0), cKd = v3(0, 0, 0), cKs = v3(0, 0, 0), kd = v3(0, 0, 0);
-    float alpha = 0.0f, zs = 0.0f;
-    float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-    ChildRay c_refr, c_refl, c_mc;
-    bool p_refr = false, p_refl = false, p_mc = false, p_gather = false, refl_below = false;
-    c_refr.o = c_refr.d = c_refr.w = c_refl.o = c_refl.d = c_refl.w = c_mc.o = c_mc.d = c_mc.w = v3(0, 0, 0);
-    c_refr.meta = c_refl.meta = c_mc.meta = 0;
-    V3 wk = v3(0, 0, 0);
-
-    if (valid) {
-      float4 h0;
-      if (reshade) {  // the hit record k_shade wrote for this entry (lights.cpp:172-183)
-        h0 = Q.h0[idx];
-        h1 = Q.h1[idx];
-        h2 = Q.h2[idx];
-      } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
-        SPHASE(2);
-        Best B;
-        unpack_raw(raw0, raw_face, B);
-        Hit h;
-        finalize_hit_from(S, S.sinst, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
-        h0 = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-        h1 = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
-        h2 = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float((h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8)));
-        if (bounce == 0 && F.hit_node && (int)m.z == P.aov_sample) {
-          F.hit_node[pixel] = h.light >= 0 ? -2 - h.light : (h.inst >= 0 ? S.sinst[h.inst].node : -1);
-          F.hit_face[pixel] = h.light >= 0 ? -1 : h.face;
-        }
-      }
-      SPHASE(3);
-      w = v3(q0.w, q1.w, q2.w);
-      V3 pabs = v3(q2.x, q2.y, q2.z);
-      V3 rdir = v3(q1.x, q1.y, q1.z);
-      int inst = (int)__float_as_uint(h1.w);
-      uint32_t flags = __float_as_uint(h2.w);
-      int light = (int)((flags >> 8) & 0xFFFFu) - 1;
-      bool front = flags & 1u;
-      float z = h0.w;
-      if (inst < 0 && light < 0) {  // miss
-        if (bounce == 0) {          // RayTracer.cpp:253-258
-          float u = (float)(pixel % (uint32_t)P.W) / (float)P.W;
-          float v = (float)(pixel / (uint32_t)P.W) / (float)P.H;
-          V3 bg = eval_tex_color<CNT>(S, S.background, v3(u, v, 0.0f), cnt);
-          aov_a = bg;
-          add_radiance(F, slot, w * bg);
-        } else {                    // lights.cpp:204-208, dist = BIGFLOAT
-          V3 c = eval_environment<CNT>(S, S.environment, rdir, cnt);
-          add_radiance(F, slot, w * absorb(c, pabs, RT_BIG));
-        }
-      } else if (light >= 0) {
-        aov_z = z * length(rdir);
-        if (bounce == 0) {          // RayTracer.cpp:243-251 / lights.h:60
-          const DLight& L = S.lights[light];
-          V3 c = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / (RT_PI_F * L.size * L.size);
-          add_radiance(F, slot, w * c);
-        } else {                    // lights.cpp:199-202
-          add_radiance(F, slot, w * absorb(v3(1, 1, 1), pabs, z));
-        }
-      } else {
-        // SamplerInfo::SetHit, renderer.h:142-150
-        zs = z * length(rdir);
-        sp.N = normalized(v3(h1.x, h1.y, h1.z));
-        V3 nd = normalized(rdir);
-        sp.V = -nd;
-        sp.P = v3(h0.x, h0.y, h0.z);
-        sp.uvw = v3(h2.x, h2.y, h2.z);
-        sp.front = front;
-        if (bounce > 0) {  // lights.cpp:194 and materials.cpp:255-259 / 277-281, applied to this subtree's weight
-          float dist = reshade ? 0.0f : (front ? zs : 0.0f);
-          w = absorb(w, pabs, dist);
-        }
-        n_shades++;
-        aov_z = zs; aov_n = sp.N;
-        const DMaterial& M = S.sinst[inst].mtl;
-        if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
-          add_radiance(F, slot, w);
-        } else {
-          surface = true;
-          SPHASE(4);
-          // materials.cpp:231-236
-          // (one copy of the texture code in a loop that is not unrolled, results routed by selects, was measured: the
-          // kernel shrinks by a third and runs 5 % SLOWER on C2 — the six inlined copies stay)
-          V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
-          V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
-          kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
-          V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
-          alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
-          V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
-          aov_a = kd;
-          float diffScalar = (float)(1 / RT_PI_D);
-          float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
-          cKd = kd * diffScalar;
-          cKs = ks * specScalar;
-          V3 fullReflection = reflection;
-          mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
-          bool can_bounce = (int)bounce < P.max_bounces;
-          float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
-          bool have_r0 = false, have_r1 = false;
-          float mior = M.ior, mgloss = M.glossiness.v;
-
-          SPHASE(5);
-          if (mior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
-            float iorRatio = (1.0f - mior) / (1.0f + mior);
-            V3 fresnel = refraction * (iorRatio * iorRatio);
-            fullReflection = fullReflection + fresnel;
-            V3 wc = w * (refraction * (v3(1, 1, 1) - fullReflection));
-            if (nonzero(wc)) {
-              shade_draws(P, sp, 0, r0); have_r0 = true;
-              shade_draws(P, sp, 1, r1); have_r1 = true;
-              refract_ray(S, sp, mior, mgloss, r0, r1, c_refr.o, c_refr.d);
-              c_refr.w = wc;
-              c_refr.meta = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
-              p_refr = true;
-            }
-          }
-          SPHASE(6);
-          if (nonzero(fullReflection) && can_bounce) {  // materials.cpp:272-285; scaled by `reflection` only
-            V3 wc = w * reflection;
-            if (nonzero(wc)) {
-              if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
-              c_refl.d = reflect_dir(S, sp, mgloss, r0[2], r0[3]);
-              c_refl.o = sp.P;
-              c_refl.w = wc;
-              refl_below = dot(c_refl.d, sp.N) < 0;  // lights.cpp:174: re-shade the same point with the new view direction
-              c_refl.meta = RT_META(nid * 4 + 2, bounce + 1, 1, refl_below ? 1 : 0);
-              p_refl = true;
-            }
-          }
-          SPHASE(7);
-          V3 local = emission;
-          if (MC && P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
-            V3 wc = w * kd;
-            if (nonzero(wc)) {
-              if (!have_r1) { shade_draws(P, sp, 1, r1); have_r1 = true; }
-              int hi = (sp.sample * P.mc_samples) % 1000;
-              float u1 = wrap01(S.halton[RT_HPHI + hi] + r1[2]);
-              float u2 = wrap01(S.halton[RT_HTHETA + hi] + r1[3]);
-              float r = sqrtf(u1);
-              float phi = two_pi_times(u2);
-              float sn, cs;
-              sincosf(phi, &sn, &cs);
-              float x = r * cs, y = r * sn, zz = sqrtf(1.0f - u1);
-              V3 t, b;
-              orthonormals(sp.N, t, b);
-              c_mc.d = normalized((x * t) + (y * b) + (zz * sp.N));
-              c_mc.o = sp.P;
-              c_mc.w = wc;
-              c_mc.meta = RT_META(nid * 4 + 3, bounce + 1, 1, 0);
-              p_mc = true;
-            }
-          } else if (PH && P.photons) {  // materials.cpp:315-322
-            wk = w * ((float)(1.0f / RT_PI_D) * kd);
-            p_gather = nonzero(wk);
-          }
-          add_radiance(F, slot, w * local);
-        }
-      }
-    }
-
-    SPHASE(8);
-    if (aov) {
-      F.aov_depth[pixel] = aov_z;
-      F.aov_normal[3 * (size_t)pixel] = aov_n.x; F.aov_normal[3 * (size_t)pixel + 1] = aov_n.y; F.aov_normal[3 * (size_t)pixel + 2] = aov_n.z;
-      F.aov_albedo[3 * (size_t)pixel] = aov_a.x; F.aov_albedo[3 * (size_t)pixel + 1] = aov_a.y; F.aov_albedo[3 * (size_t)pixel + 2] = aov_a.z;
-    }
-    // ---- queue appends (all lanes of the wave pass through here); the three kinds of children share one atomic
-    {
-      uint32_t cpos[3];
-      seg_push3(p_refr, p_refl, MC && p_mc, QN.counts, oseg, QN.segcap, F.overflow, cpos);
-      if (cpos[0] != RT_NONE) write_child(QN, cpos[0], c_refr, mabs, slot, pixel, m.z);
-      if (cpos[1] != RT_NONE) {
-        write_child(QN, cpos[1], c_refl, mabs, slot, pixel, m.z);
-        if (refl_below) {
-          QN.h0[cpos[1]] = make_float4(sp.P.x, sp.P.y, sp.P.z, zs);
-          QN.h1[cpos[1]] = make_float4(sp.N.x, sp.N.y, sp.N.z, h1.w);
-          QN.h2[cpos[1]] = h2;
-        }
-      }
-      if (MC && cpos[2] != RT_NONE) write_child(QN, cpos[2], c_mc, v3(0, 0, 0), slot, pixel, m.z);  // `dist` is unused by the sampler: no absorption
-    }
-
-    SPHASE(9);
-    // light loop, materials.cpp:288-307: unshadowed term now, visibility from the shadow kernels
-    for (int li = 0; li < S.n_lights; li++) {
-      RT_UTYPE(DLight)* L = lights + li;
-      int kind = L->kind;
-      if (kind == 1) continue;  // ambient is accumulated and never added  [uniform branch]
-      bool soft = false, lit = false;
-      V3 contrib = v3(0, 0, 0);
-      float rx = 0, ry = 0;
-      if (kind == 3) soft = (L->size * P.light_size_scale) != 0.0f;
-      if (surface) {
-        V3 lightDir, inten = v3(L->intensity[0], L->intensity[1], L->intensity[2]);
-        if (kind == 2) {  // lights.h:45
-          lightDir = -v3(L->direction[0], L->direction[1], L->direction[2]);
-        } else {          // lights.cpp:62-71
-          V3 dl = v3(L->position[0], L->position[1], L->position[2]) - sp.P;
-          float dist = length(dl);
-          lightDir = normalized(dl);
-          if (L->attenuation != 0.0f) inten = inten / (dist * dist);
-        }
-        V3 h = normalized(lightDir + sp.V);
-        float cosphi = fmaxf(dot(sp.N, h), 0.0f);
-        float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
-        // (0 * powf(..) is +0 for every finite power of a cosine in [0, 1]: a wave of purely diffuse points skips powf)
-        const float spec = nonzero(cKs) ? powf(cosphi, alpha) : 0.0f;
-        contrib = w * (inten * ((costheta * cKd) + (cKs * spec)));
-        lit = nonzero(contrib);
-        if (lit && soft) {
-          float rl[4];
-          shade_draws(P, sp, 2 + (uint32_t)li, rl);
-          rx = rl[0]; ry = rl[1];
-        }
-      }
-      if (soft) {
-        uint32_t gi = seg_push(lit, GS.counts, oseg, GS.segcap, F.overflow);
-        if (gi != RT_NONE) {
-          GS.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
-          GS.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
-          GS.g2[gi] = make_float4(rx, ry, __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));   // (.w: instances 32..63 that may occlude)
-          V3 toSP = normalized(sp.P - v3(L->position[0], L->position[1], L->position[2]));  // lights.cpp:21-22, 31-32
-          V3 tangent, bitangent;
-          orthonormals(toSP, tangent, bitangent);
-          GS.g3[gi] = make_float4(tangent.x, tangent.y, tangent.z, L->size * P.light_size_scale);
-          GS.g4[gi] = make_float4(bitangent.x, bitangent.y, bitangent.z, __uint_as_float(0xFFFFFFFFu));   // (.w: instances 0..31 that may occlude, k_shadow_soft_clear)
-        }
-      } else {
-        uint32_t gi = seg_push(lit, GH.counts, oseg, GH.segcap, F.overflow);
-        if (gi != RT_NONE) {
-          GH.g0[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float((uint32_t)li));
-          GH.g1[gi] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
-        }
-      }
-    }
-    SPHASE(10);
-    if (PH && P.photons) {
-      uint32_t gi = seg_push(p_gather, GQ.counts, oseg, GQ.segcap, F.overflow);
-      if (gi != RT_NONE) {
-        GQ.a[gi] = make_float4(sp.P.x, sp.P.y, sp.P.z, __uint_as_float(slot));
-        GQ.b[gi] = make_float4(sp.N.x, sp.N.y, sp.N.z, __uint_as_float(secondary ? 1u : 0u));
-        GQ.c[gi] = make_float4(wk.x, wk.y, wk.z, 0.0f);
-      }
-    }
-    SPHASE(0);
+    Best B;
+    unpack_raw(raw0, raw_face, B);
+    shade_point<CNT, MC, PH>(S, P, F, Q, idx, QN, GH, GS, GQ, oseg, seg_valid, m, q0, q1, q2, B, cnt, n_shades);
   RT_SEG_END
-#ifdef RT_SHADE_STATS
-  SPHASE(0);
-  if (rt_lane() == 0) for (int i = 0; i < 16; i++) if (ss[i]) atomicAdd(&g_shade_stats[i], ss[i]);
-#endif
   if (CNT) {
     cnt.flush(F.counters);
+    if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ trace + shade, fused
+// The first trace phase and the shading of the rays it finishes, in one kernel.  A ray whose path reaches no mesh box has its
+// closest hit after the instance table (spheres, planes, light spheres): it is shaded right there, from registers — it is never
+// written to a ray queue, its raw hit never stored and never read back (84 B written + 84 B read per ray in the two-kernel
+// form, for three quarters of C2's rays and all of C3's).  A ray with mesh candidates is appended to the compact queue QM
+// (entry + work item at the same index, one atomic per wave), walked by k_trace_mesh and shaded by k_shade, which then
+// sees nothing but mesh hits.  Children of both go to QN, in the parent's segment.
+template <bool CNT, bool TLAS, bool MC, bool PH>
+RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint32_t* l0_counts, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS,
+            GatherQ GQ) {
+  RT_STACK_DECL
+  Cnt<CNT> cnt;
+  uint32_t traced = 0, n_shades = 0;
+  const uint32_t total = P.n_pix * (uint32_t)P.n_samples;
+  const uint32_t nseg = QN.nseg;
+  for (uint32_t idx = RT_TID; (idx & ~63u) < total; idx += RT_NTHREADS) {
+    const bool valid = idx < total;
+    const uint32_t seg = (idx / 64u) % nseg;   // 64-path tiles (8x8 pixels of one sample) are dealt round-robin to the segments
+    uint32_t head = RT_NONE;
+    Best B;
+    best_init(B);
+    V3 o = v3(0, 0, 0), dir = v3(1, 0, 0);
+    uint4 m;
+    m.x = m.y = m.z = m.w = 0;
+    if (valid) {
+      uint32_t pixel;
+      int i;
+      primary_ray(S, P, F, idx, o, dir, pixel, i);
+      m.x = idx; m.y = pixel; m.z = (uint32_t)i; m.w = RT_META(1, 0, 0, 0);
+      F.path_rad[idx] = 0.0f; F.path_rad[(size_t)F.rad_stride + idx] = 0.0f; F.path_rad[2 * (size_t)F.rad_stride + idx] = 0.0f;
+      traced++;
+    }
+    // primary rays see front faces only (RayTracer.cpp:233)
+    const CandSink K = cand_sink(MQ, seg, F.overflow);
+    if (TLAS) { if (valid) closest_instances_tlas<CNT, true>(S, o, dir, 1, B, head, K, stk, stride, cnt); }
+    else closest_instances<CNT, true, true>(S, o, dir, 1, B, head, K, stk, stride, cnt, valid);   // (every lane: wave-wide appends)
+    const bool to_mesh = valid && head != RT_NONE;
+    const float4 q0 = make_float4(o.x, o.y, o.z, 1.0f), q1 = make_float4(dir.x, dir.y, dir.z, 1.0f), q2 = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    const uint32_t wi = seg_push(to_mesh, QM.counts, seg, QM.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      QM.q0[wi] = q0; QM.q1[wi] = q1; QM.q2[wi] = q2; QM.q3[wi] = m;
+      uint4 it;
+      it.x = wi; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
+      MQ.item4[wi] = it;
+    }
+    shade_point<CNT, MC, PH>(S, P, F, QM, 0u, QN, GH, GS, GQ, seg, valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
+  }
+  // camera samples per segment: what the host measures the queues' fan-out against
+  const uint32_t tiles = (total + 63u) / 64u;
+  for (uint32_t sgm = RT_TID; sgm < nseg; sgm += RT_NTHREADS) {
+    uint32_t nt = tiles > sgm ? (tiles - sgm + nseg - 1u) / nseg : 0u;
+    uint32_t c = nt * 64u;
+    if (nt && (tiles - 1u) % nseg == sgm) c -= tiles * 64u - total;  // the last tile may be partial
+    l0_counts[sgm * RT_CSTRIDE] = c;
+  }
+  if (CNT) {
+    cnt.flush(F.counters);
+    cnt.flush_closest(F.counters);
+    if (traced) rt_atomic_add_u64(&F.counters->rays_primary, traced);
+    if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);
+  }
+}
+
+// Secondary rays (level >= 1): the children k_shade / the fused kernels appended to Q.
+template <bool CNT, bool TLAS, bool MC, bool PH>
+RT_KERNEL_W(RT_SHADE_WAVES, k_trace_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
+  RT_STACK_DECL
+  Cnt<CNT> cnt;
+  uint32_t traced = 0, n_shades = 0;
+  RT_SEG_BEGIN(Q.counts, Q.nseg, Q.segcap, 1u)
+    const uint32_t seg = sw_.s % QN.nseg;
+    const uint32_t idx = seg_base_ + (uint32_t)seg_e;
+    uint32_t head = RT_NONE;
+    Best B;
+    best_init(B);
+    uint4 m;
+    m.x = m.y = m.z = m.w = 0;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = make_float4(1, 0, 0, 0), q2 = q0;
+    bool trace = false;
+    if (seg_valid) {
+      m = Q.q3[idx];
+      q0 = Q.q0[idx]; q1 = Q.q1[idx]; q2 = Q.q2[idx];
+      trace = !(m.w & (1u << 16));   // (re-shade entries carry a hit record written by their parent, lights.cpp:172-183)
+      if (trace) traced++;
+    }
+    const V3 o = v3(q0.x, q0.y, q0.z), dir = v3(q1.x, q1.y, q1.z);
+    // secondary rays see both sides (lights.cpp:185)
+    const CandSink K = cand_sink(MQ, seg, F.overflow);
+    if (TLAS) { if (trace) closest_instances_tlas<CNT, true>(S, o, dir, 3, B, head, K, stk, stride, cnt); }
+    else closest_instances<CNT, true>(S, o, dir, 3, B, head, K, stk, stride, cnt, trace);   // (every lane: wave-wide appends)
+    const bool to_mesh = trace && head != RT_NONE;
+    const uint32_t wi = seg_push(to_mesh, QM.counts, seg, QM.segcap, F.overflow);
+    if (wi != RT_NONE) {
+      QM.q0[wi] = q0; QM.q1[wi] = q1; QM.q2[wi] = q2; QM.q3[wi] = m;
+      uint4 it;
+      it.x = wi; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
+      MQ.item4[wi] = it;
+    }
+    shade_point<CNT, MC, PH>(S, P, F, Q, idx, QN, GH, GS, GQ, seg, seg_valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
+  RT_SEG_END
+  if (CNT) {
+    cnt.flush(F.counters);
+    cnt.flush_closest(F.counters);
+    if (traced) rt_atomic_add_u64(&F.counters->rays_secondary, traced);
     if (n_shades) rt_atomic_add_u64(&F.counters->shades, n_shades);
   }
 }

@@ -120,6 +120,8 @@ struct Options {
   double fan_scale = 1;            // "fan_scale"    RT_TEST_FAN_SCALE  scales the measured queue sizing (tests: forces overflow)
   double timing = 0;               // "timing"       RT_TIMING        host-side phases of the photon build on stderr
   double soft_clear = 1;           // "soft_clear"   RT_SOFT_CLEAR    0: trace every soft-shadow group (tests compare both)
+  double fuse = 1;                 // "fuse"         RT_FUSE          1: first trace phase + shading in one kernel (k_raygen_shade / k_trace_shade);
+                                   //                                  0: the separate k_raygen_trace / k_trace_closest / k_shade launches
   double cone_max_inst = RT_CONE_MAX_INST;   // "cone_max_inst"  instances up to which the soft-shadow proofs walk the instance table; beyond it
                                              //                  (with an instance BVH) every group's cone walks the BVH (tests force both)
 };
@@ -156,6 +158,7 @@ struct rt_context {
   std::vector<DevMem> frame_mem;
   size_t frame_key[16] = {0};
   RayQ Q[2];
+  RayQ QM;     // rays waiting for the mesh phase (entry i belongs to work item i of MQ): k_trace_mesh writes their hit, k_shade shades them
   GroupQ GH, GS;
   GatherQ GQ;
   MeshQ MQ, MH, MS;
@@ -617,6 +620,7 @@ int rt_context_create(int device_id, rt_context** out) {
   env("RT_TEST_FAN_SCALE", ctx->opt.fan_scale);
   if (std::getenv("RT_TIMING")) ctx->opt.timing = 1;
   if (const char* e = std::getenv("RT_SOFT_CLEAR")) ctx->opt.soft_clear = std::atof(e);
+  env("RT_FUSE", ctx->opt.fuse);
   *out = ctx;
   return RT_OK;
 }
@@ -632,6 +636,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "timing") ctx->opt.timing = value;
   else if (n == "soft_clear") ctx->opt.soft_clear = value;
   else if (n == "cone_max_inst") ctx->opt.cone_max_inst = value;
+  else if (n == "fuse") ctx->opt.fuse = value;
   else if (n == "shadow_tlas_min") ctx->opt.shadow_tlas_min = value;   // takes effect at the next rt_scene_commit
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
   return RT_OK;
@@ -1661,6 +1666,20 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     return r;
   };
   if ((rc = alloc_meshq(ctx->MQ, fp.f[4], fp.f[7]))) return rc;
+  {  // the rays of those items (same index, same segments): ray, weights, ids, and the raw hit k_trace_mesh leaves
+    RayQ& q = ctx->QM;
+    const size_t mcap = (size_t)ctx->MQ.segcap * NSEG;
+    q.segcap = ctx->MQ.segcap;
+    q.nseg = NSEG;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 16, &p))) return rc; q.q0 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 16, &p))) return rc; q.q1 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 16, &p))) return rc; q.q2 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 16, &p))) return rc; q.q3 = (uint4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 16, &p))) return rc; q.r0 = (float4*)p;
+    if ((rc = alloc_dev(ctx, ctx->frame_mem, mcap * 4, &p))) return rc; q.rf = (uint32_t*)p;
+    q.h0 = q.h1 = q.h2 = nullptr;   // (re-shade entries never wait for the mesh phase)
+    q.counts = nullptr;
+  }
   if ((rc = alloc_meshq(ctx->MH, fp.n_hard ? fp.f[5] : 0.0, fp.f[8]))) return rc;
   if ((rc = alloc_meshq(ctx->MS, fp.n_soft ? fp.f[6] : 0.0, fp.f[9]))) return rc;
   if ((rc = alloc_dev(ctx, ctx->frame_mem, (size_t)fp.budget * 12, &p))) return rc;
@@ -1715,7 +1734,12 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     q.cand_counts = ctx->d_counts + cnt_at(lvl, kind_cnt == CNT_MQ ? CNT_CQ : (kind_cnt == CNT_MH ? CNT_CH : (kind_cnt == CNT_MS1 ? CNT_CS1 : CNT_CS2)));
     return q;
   };
-  {  // camera rays + their first phase (instance table)
+  // (measured, MI355X: fused C1 0.196 -> 0.174, C3 46.4 -> 42.8, C4 43.8 -> 42.8, C2 15.94 -> 15.77 ms per step; scenes whose
+  //  closest-hit rays walk the instance BVH per lane lose — 2944 spheres 7.19 -> 7.98 ms: that walk wants the trace kernels'
+  //  higher occupancy — and keep the separate kernels)
+  const bool fuse = ctx->opt.fuse != 0 && !ctx->ds.use_tlas;
+  const bool mc = P.mc_bounces > 0, ph = P.photons != 0;
+  if (!fuse) {  // camera rays + their first phase (instance table)
     MeshQ MQ = meshq(ctx->MQ, 0, CNT_MQ, CUR_MQ);
     Timer t(ctx, RT_K_RAYGEN);
     if (ctx->ds.use_tlas) LAUNCH_T((k_raygen_trace<CNT, true>), n0, ctx->ds, P, F, Qc, MQ);
@@ -1734,28 +1758,66 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     GQ.counts = ctx->d_counts + cnt_at(lvl, CNT_GQ);
     uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
-    {
+    if (fuse) {
+      // first trace phase + shading of the rays it finishes in ONE kernel; the rays that reach a mesh box go through QM / MQ
+      // (entry and work item at the same index: the queue's length words are the item queue's)
       MeshQ MQ = meshq(ctx->MQ, lvl, CNT_MQ, CUR_MQ);
-      if (lvl > 0) {  // (level 0 went through k_raygen_trace)
+      RayQ QM = ctx->QM;
+      QM.counts = MQ.counts;
+#define RT_FUSED(kern, ...)                                                                                     \
+      do {                                                                                                      \
+        if (mc && ph) LAUNCH_P1((kern<CNT, false, true, true>), __VA_ARGS__);                                   \
+        else if (mc) LAUNCH_P1((kern<CNT, false, true, false>), __VA_ARGS__);                                   \
+        else if (ph) LAUNCH_P1((kern<CNT, false, false, true>), __VA_ARGS__);                                   \
+        else LAUNCH_P1((kern<CNT, false, false, false>), __VA_ARGS__);                                          \
+      } while (0)
+      if (lvl == 0) {
+        Timer t(ctx, RT_K_RAYGEN);
+        RT_FUSED(k_raygen_shade, n0, ctx->ds, P, F, ctx->d_counts + cnt_at(0, CNT_Q), QM, MQ, Qn, GH, GS, GQ);
+        t.stop((1ull << 32) + n0);
+      } else {
         Timer t(ctx, RT_K_TRACE_CLOSEST);
-        if (ctx->ds.use_tlas) LAUNCH_T((k_trace_closest<CNT, true>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
-        else LAUNCH_P1((k_trace_closest<CNT, false>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+        RT_FUSED(k_trace_shade, ubn, ctx->ds, P, F, Qc, QM, MQ, Qn, GH, GS, GQ);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
       }
+#undef RT_FUSED
       if (meshes) {
-        Timer t2(ctx, RT_K_TRACE_MESH);
-        LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
-        t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
+        const uint64_t mub = std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg);
+        {
+          Timer t2(ctx, RT_K_TRACE_MESH);
+          LAUNCH_T(k_trace_mesh<CNT>, mub, ctx->ds, P, F, QM, MQ, lvl);
+          t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
+        }
+        Timer t(ctx, RT_K_SHADE);
+        if (mc && ph) LAUNCH((k_shade<CNT, true, true>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
+        else if (mc) LAUNCH((k_shade<CNT, true, false>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
+        else if (ph) LAUNCH((k_shade<CNT, false, true>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
+        else LAUNCH((k_shade<CNT, false, false>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
+        t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
       }
-    }
-    {
-      Timer t(ctx, RT_K_SHADE);
-      const bool mc = P.mc_bounces > 0, ph = P.photons != 0;
-      if (mc && ph) LAUNCH((k_shade<CNT, true, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-      else if (mc) LAUNCH((k_shade<CNT, true, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-      else if (ph) LAUNCH((k_shade<CNT, false, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-      else LAUNCH((k_shade<CNT, false, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+    } else {
+      {
+        MeshQ MQ = meshq(ctx->MQ, lvl, CNT_MQ, CUR_MQ);
+        if (lvl > 0) {  // (level 0 went through k_raygen_trace)
+          Timer t(ctx, RT_K_TRACE_CLOSEST);
+          if (ctx->ds.use_tlas) LAUNCH_T((k_trace_closest<CNT, true>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+          else LAUNCH_P1((k_trace_closest<CNT, false>), ubn, ctx->ds, P, F, Qc, MQ, lvl);
+          t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+        }
+        if (meshes) {
+          Timer t2(ctx, RT_K_TRACE_MESH);
+          LAUNCH_T(k_trace_mesh<CNT>, std::min<uint64_t>(ubn, (uint64_t)MQ.segcap * MQ.nseg), ctx->ds, P, F, Qc, MQ, lvl);
+          t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
+        }
+      }
+      {
+        Timer t(ctx, RT_K_SHADE);
+        if (mc && ph) LAUNCH((k_shade<CNT, true, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+        else if (mc) LAUNCH((k_shade<CNT, true, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+        else if (ph) LAUNCH((k_shade<CNT, false, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+        else LAUNCH((k_shade<CNT, false, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+        t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
+      }
     }
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
@@ -2441,19 +2503,6 @@ int rt_counters_get(rt_context* ctx, rt_counters* out) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out, ctx->d_counters, sizeof(rt_counters), hipMemcpyDeviceToHost));
   out->paths += ctx->host_paths;
-#ifdef RT_SHADE_STATS
-  {
-    unsigned long long ss[16];
-    if (hipMemcpyFromSymbol(ss, HIP_SYMBOL(g_shade_stats), sizeof ss) == hipSuccess) {
-      static const char* nm[11] = {"claim/loop", "entry load", "finalize_hit", "miss/light/setup", "textures", "refraction", "reflection", "mc/emission", "aov+children", "light loop", "gather push"};
-      double tt = 0;
-      for (int i = 0; i < 11; i++) tt += (double)ss[i];
-      std::fprintf(stderr, "shade cycles:");
-      for (int i = 0; i < 11; i++) std::fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)ss[i] / (tt > 0 ? tt : 1));
-      std::fprintf(stderr, " (total %.3g wave-cycles)\n", tt);
-    }
-  }
-#endif
 #ifdef RT_WALK_STATS
   {
     unsigned long long ws[16];
