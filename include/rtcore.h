@@ -260,6 +260,18 @@ typedef struct rt_context rt_context;
 int rt_context_create(int device_id, rt_context** out);
 void rt_context_destroy(rt_context* ctx);
 const char* rt_last_error(const rt_context* ctx);
+/* A host that drives several GPUs from ONE process (the reference starts hardware_concurrency() threads on one renderer,
+ * RayTracer.cpp:41-50; its multi-GPU counterpart is one context per GPU): creates n_devices contexts, out[i] on
+ * device_ids[i] (device_ids NULL = devices 0 .. n_devices-1).  Each context is single-owner with its own stream, so the host
+ * may drive them from one thread (rt_render_accumulate enqueues and returns) or from one thread each; their accumulators
+ * are summed with rt_reduce_accumulators or by the host.  All or nothing: on failure every context created so far is
+ * destroyed and out[] is nulled.  A device id may appear once. */
+int rt_context_create_multi(int n_devices, const int* device_ids, rt_context** out);
+/* Page-locked host memory for the caller-owned buffers of rt_framebuffer / rt_trace_* / rt_photons_download (the
+ * reference's RenderImage owns plain `new` arrays, renderer.h:35-46; with pinned memory the device-to-host copies at the
+ * end of rt_render run at full PCIe rate and without a staging copy).  Freed with rt_free_pinned only. */
+int rt_alloc_pinned(size_t bytes, void** out);
+void rt_free_pinned(void* p);
 
 /* Replaces the in-memory hand-over at the end of Renderer::LoadScene (xmlload.cpp:70-72):
  * the flattened scene is copied to the device, instance chains and acceleration data are built. */

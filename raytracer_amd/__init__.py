@@ -152,16 +152,48 @@ class _SceneView:
 class RenderImage:
     """Output buffers (reference RenderImage, RayTracer/renderer.h:35-103)."""
 
-    def __init__(self, w, h):
+    def __init__(self, w, h, pinned_lib=None):
+        """pinned_lib: the loaded librtcore — the arrays then live in page-locked host memory (rt_alloc_pinned), which the
+        device-to-host copies at the end of rt_render fill without a staging copy."""
         self.width, self.height = w, h
-        self.img = np.zeros((h, w, 3), np.uint8)
-        self.radiance = np.zeros((h, w, 4), np.float32)
-        self.sample_count = np.zeros((h, w), np.int32)
-        self.hit_node = np.full((h, w), -1, np.int32)
-        self.hit_face = np.full((h, w), -1, np.int32)
-        self.zbuffer = np.zeros((h, w), np.float32)       # RenderImage::zbuffer (renderer.h:39)
-        self.normal = np.zeros((h, w, 3), np.float32)
-        self.albedo = np.zeros((h, w, 3), np.float32)
+        self._pinned = []
+        self._lib = pinned_lib
+
+        def arr(shape, dtype, fill=0):
+            if pinned_lib is None:
+                return np.full(shape, fill, dtype)
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            ptr = C.c_void_p()
+            if pinned_lib.rt_alloc_pinned(n, C.byref(ptr)) != 0:
+                raise RuntimeError("rt_alloc_pinned failed")
+            self._pinned.append(ptr)
+            a = np.frombuffer((C.c_char * n).from_address(ptr.value), dtype=dtype).reshape(shape)
+            a[...] = fill
+            return a
+
+        self.img = arr((h, w, 3), np.uint8)
+        self.radiance = arr((h, w, 4), np.float32)
+        self.sample_count = arr((h, w), np.int32)
+        self.hit_node = arr((h, w), np.int32, -1)
+        self.hit_face = arr((h, w), np.int32, -1)
+        self.zbuffer = arr((h, w), np.float32)       # RenderImage::zbuffer (renderer.h:39)
+        self.normal = arr((h, w, 3), np.float32)
+        self.albedo = arr((h, w, 3), np.float32)
+
+    def release(self):
+        """Pinned images only: hands the page-locked memory back (the arrays must not be used afterwards)."""
+        for name in ("img", "radiance", "sample_count", "hit_node", "hit_face", "zbuffer", "normal", "albedo"):
+            if self._pinned:
+                setattr(self, name, np.array(getattr(self, name)))   # detach: plain copies stay usable
+        for ptr in self._pinned:
+            self._lib.rt_free_pinned(ptr)
+        self._pinned = []
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def framebuffer(self):
         fb = rt_framebuffer()
@@ -184,18 +216,30 @@ class RenderImage:
 class Renderer:
     """Drop-in for the reference's RayTracer : Renderer (RayTracer/raytracer.h:14-61) on one MI355X."""
 
-    def __init__(self, device_id=0, _lib=None):
+    def __init__(self, device_id=0, _lib=None, _ctx=None):
         # _lib: tests pass the host-emulation build of the same sources (tests/_emu); the package itself only
         # ever loads librtcore.so and raises if it is missing.
         self._lib = _lib if _lib is not None else _ffi.load_core()
-        ctx = C.c_void_p()
-        rc = self._lib.rt_context_create(device_id, C.byref(ctx))
-        if rc != 0:
-            raise RuntimeError(f"rt_context_create failed ({rc})")
+        ctx = _ctx if _ctx is not None else C.c_void_p()
+        if _ctx is None:
+            rc = self._lib.rt_context_create(device_id, C.byref(ctx))
+            if rc != 0:
+                raise RuntimeError(f"rt_context_create failed ({rc})")
         self._ctx = ctx
         self.scene = None
         self.renderImage = None
         self.params = default_params()
+
+    @classmethod
+    def create_multi(cls, device_ids, _lib=None):
+        """One renderer per GPU of a single-process host (rt_context_create_multi: all contexts or none)."""
+        lib = _lib if _lib is not None else _ffi.load_core()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        out = (C.c_void_p * len(device_ids))()
+        rc = lib.rt_context_create_multi(len(device_ids), ids, out)
+        if rc != 0:
+            raise RuntimeError(f"rt_context_create_multi failed ({rc})")
+        return [cls(d, _lib=lib, _ctx=C.c_void_p(out[i])) for i, d in enumerate(device_ids)]
 
     def _check(self, rc, what):
         if rc != 0:
@@ -250,12 +294,12 @@ class Renderer:
         self._check(self._lib.rt_render_wait(self._ctx), "rt_render_wait")
         return self.renderImage
 
-    def Render(self, params=None):
-        """Blocking BeginRender + StopRender."""
+    def Render(self, params=None, pinned=False):
+        """Blocking BeginRender + StopRender.  pinned: the output images in page-locked host memory (rt_alloc_pinned)."""
         params = params or self.params
         w, h = self._dims(params)
         self._join()
-        self.renderImage = RenderImage(w, h)
+        self.renderImage = RenderImage(w, h, self._lib if pinned else None)
         fb = self.renderImage.framebuffer()
         self._check(self._lib.rt_render(self._ctx, C.byref(params), C.byref(fb)), "rt_render")
         return self.renderImage

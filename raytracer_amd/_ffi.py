@@ -204,7 +204,7 @@ CORE_SYMBOLS = [
     "rt_photons_build", "rt_photons_download", "rt_photons_set", "rt_photon_gather", "rt_denoise", "rt_counters_enable",
     "rt_counters_reset", "rt_counters_get", "rt_profile_enable", "rt_profile_reset", "rt_profile_get",
     "rt_render_params_default", "rt_set_option", "rt_debug_alloc_count", "rt_denoise_noalloc", "rt_photons_download_tree", "rt_reduce_accumulators",
-    "rt_scene_mesh_bvh", "rt_debug_philox",
+    "rt_scene_mesh_bvh", "rt_debug_philox", "rt_context_create_multi", "rt_alloc_pinned", "rt_free_pinned",
 ]
 HOST_SYMBOLS = [
     "rth_scene_load_file", "rth_scene_load_string", "rth_scene_free", "rth_last_error", "rth_scene_desc",
@@ -255,6 +255,10 @@ def bind_core(lib):
     vp = C.c_void_p
     lib.rt_context_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.rt_context_destroy.argtypes = [vp]
+    lib.rt_context_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.rt_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.rt_free_pinned.argtypes = [vp]
+    lib.rt_free_pinned.restype = None
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_last_error.argtypes = [vp]
     lib.rt_scene_commit.argtypes = [vp, C.POINTER(rt_scene_desc)]

@@ -670,6 +670,35 @@ void rt_context_destroy(rt_context* ctx) {
 
 const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int rt_context_create_multi(int n_devices, const int* device_ids, rt_context** out) {
+  if (!out || n_devices <= 0 || n_devices > 64) return RT_ERR_INVALID;
+  for (int i = 0; i < n_devices; i++) out[i] = nullptr;
+  for (int i = 0; i < n_devices; i++)
+    for (int j = 0; j < i; j++)
+      if ((device_ids ? device_ids[i] : i) == (device_ids ? device_ids[j] : j)) return RT_ERR_INVALID;   // one context per GPU
+  for (int i = 0; i < n_devices; i++) {
+    const int rc = rt_context_create(device_ids ? device_ids[i] : i, &out[i]);
+    if (rc != RT_OK) {
+      for (int j = 0; j < i; j++) { rt_context_destroy(out[j]); out[j] = nullptr; }
+      return rc;
+    }
+  }
+  return RT_OK;
+}
+
+int rt_alloc_pinned(size_t bytes, void** out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return RT_ERR_INVALID;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes) != hipSuccess || !p) return RT_ERR_DEVICE;
+  *out = p;
+  return RT_OK;
+}
+void rt_free_pinned(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if (!ctx) return RT_ERR_INVALID;
   if (!sc || !sc->nodes || sc->n_nodes == 0) return fail(ctx, RT_ERR_INVALID, "scene has no nodes");

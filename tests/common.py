@@ -159,6 +159,43 @@ UNLIT_SCENE = """<xml><scene>
 <width value="40"/><height value="30"/></camera></xml>"""
 
 
+def check_boundary_extras(r):
+    """rt_alloc_pinned / rt_free_pinned and rt_context_create_multi: a frame rendered into page-locked images equals
+    the frame rendered into plain arrays; a context made by the multi-device call renders the same frame; duplicate or bad
+    device ids fail and leave nothing behind."""
+    import ctypes as C
+    from conftest import scene_path
+    from raytracer_amd import Renderer, Scene
+    lib = r._lib
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    r.LoadScene(scene)
+    p = params(96, 64, spp=2, jitter=1, bounces=2)
+    a = r.Render(p)
+    b = r.Render(p, pinned=True)
+    assert len(b._pinned) == 8
+    for name in ("img", "sample_count", "hit_node", "hit_face"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.allclose(a.radiance, b.radiance, rtol=1e-5, atol=1e-6) and np.allclose(a.zbuffer, b.zbuffer)
+    kept = b.radiance
+    b.release()
+    assert b._pinned == [] and np.array_equal(np.asarray(b.radiance), np.asarray(b.radiance)) and kept is not b.radiance
+    ptr = C.c_void_p()
+    assert lib.rt_alloc_pinned(0, C.byref(ptr)) != 0 and not ptr.value
+    assert lib.rt_alloc_pinned(4096, None) != 0
+    lib.rt_free_pinned(None)
+    (r2,) = Renderer.create_multi([0], _lib=lib)
+    r2.LoadScene(scene)
+    c = r2.Render(p)
+    assert np.array_equal(a.hit_node, c.hit_node) and np.allclose(a.radiance, c.radiance, rtol=1e-5, atol=1e-6)
+    r2.close()
+    out = (C.c_void_p * 2)()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.rt_context_create_multi(2, ids, out) != 0 and not out[0] and not out[1]        # one context per GPU
+    ids = (C.c_int * 2)(0, 1 << 20)
+    assert lib.rt_context_create_multi(2, ids, out) != 0 and not out[0] and not out[1]        # all or nothing
+    assert lib.rt_context_create_multi(0, None, out) != 0 and lib.rt_context_create_multi(1, None, None) != 0
+
+
 def check_edge_cases(r):
     """Empty scene, scene without lights, a default-material node, ragged image sizes (partial 32x32 tiles,
     partial 64-path wave tiles), 1x1 image, empty ray batches."""
