@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -442,6 +443,12 @@ struct orc_scene {
   bool photons_built = false;
   rt_material default_mtl;
   bool accel = false;   // orc_set_accel: ordered, pruned BVH traversal (second CPU baseline row; not the reference's structure)
+  // ... and, with orc_set_accel, a BVH over the primitive nodes' world boxes in place of the Theta(nodes) scene-graph walk
+  struct InstNode { float b[6]; int left, right, first, count; };
+  std::vector<InstNode> inst_bvh;
+  std::vector<int> inst_order;                 // primitive node indices in leaf order
+  std::vector<std::vector<int>> inst_chain;    // per node: the node indices root .. node
+  std::vector<float> inst_box;                 // per node: world box (6 floats)
 };
 
 namespace {
@@ -909,6 +916,177 @@ bool traverse_shadow(const orc_scene& S, const Ray& ray, int node, float t_max, 
   return false;
 }
 
+// ---- second CPU baseline row, scene-graph half (orc_set_accel): the primitive nodes in a BVH over their world boxes, walked
+// front to back with pruning — what the GPU's instance BVH does — instead of TraverseTree's test of every node.  TIMING
+// ONLY: equal-t ties may resolve differently from the depth-first order; parity checks never run with it.
+void build_inst_bvh(orc_scene& S) {
+  const uint32_t n = S.d.n_nodes;
+  S.inst_chain.assign(n, {});
+  S.inst_box.assign((size_t)n * 6, 0.0f);
+  S.inst_order.clear();
+  S.inst_bvh.clear();
+  for (uint32_t i = 0; i < n; i++) {
+    const rt_node& nd = S.d.nodes[i];
+    std::vector<int> chain;
+    for (int k = (int)i; k >= 0; k = S.d.nodes[k].parent) chain.push_back(k);
+    std::reverse(chain.begin(), chain.end());
+    S.inst_chain[i] = chain;
+    if (nd.prim_kind == RT_PRIM_NONE) continue;
+    float lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+    if (nd.prim_kind == RT_PRIM_PLANE) { lo[2] = -1e-3f; hi[2] = 1e-3f; }
+    if (nd.prim_kind == RT_PRIM_MESH) {
+      const rt_bvh_node& r = S.d.meshes[nd.mesh_id].bvh[0];
+      for (int a = 0; a < 3; a++) { lo[a] = r.bmin[a]; hi[a] = r.bmax[a]; }
+    }
+    float* b = &S.inst_box[(size_t)i * 6];
+    for (int a = 0; a < 3; a++) { b[a] = BIGFLOAT; b[3 + a] = -BIGFLOAT; }
+    for (int c = 0; c < 8; c++) {
+      V q((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]);
+      for (int k = (int)chain.size() - 1; k >= 0; k--) q = xform_point(S.d.nodes[chain[k]].tm, q);
+      const float w[3] = {q.x, q.y, q.z};
+      for (int a = 0; a < 3; a++) { b[a] = std::min(b[a], w[a]); b[3 + a] = std::max(b[3 + a], w[a]); }
+    }
+    for (int a = 0; a < 3; a++) {   // padded: the transforms round
+      const float pad = 1e-4f * (std::fabs(b[a]) + std::fabs(b[3 + a])) + 1e-4f;
+      b[a] -= pad; b[3 + a] += pad;
+    }
+    S.inst_order.push_back((int)i);
+  }
+  if (S.inst_order.empty()) return;
+  std::function<int(int, int)> build = [&](int first, int count) -> int {
+    orc_scene::InstNode nd;
+    for (int a = 0; a < 3; a++) { nd.b[a] = BIGFLOAT; nd.b[3 + a] = -BIGFLOAT; }
+    float clo[3] = {BIGFLOAT, BIGFLOAT, BIGFLOAT}, chi[3] = {-BIGFLOAT, -BIGFLOAT, -BIGFLOAT};
+    for (int k = first; k < first + count; k++) {
+      const float* b = &S.inst_box[(size_t)S.inst_order[k] * 6];
+      for (int a = 0; a < 3; a++) {
+        nd.b[a] = std::min(nd.b[a], b[a]); nd.b[3 + a] = std::max(nd.b[3 + a], b[3 + a]);
+        const float c = 0.5f * (b[a] + b[3 + a]);
+        clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+      }
+    }
+    nd.left = nd.right = -1; nd.first = first; nd.count = count;
+    const int me = (int)S.inst_bvh.size();
+    S.inst_bvh.push_back(nd);
+    if (count > 2) {
+      int ax = 0;
+      if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+      if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+      auto key = [&](int node) { const float* b = &S.inst_box[(size_t)node * 6]; return b[ax] + b[3 + ax]; };
+      const int mid = first + count / 2;
+      std::nth_element(S.inst_order.begin() + first, S.inst_order.begin() + mid, S.inst_order.begin() + first + count,
+                       [&](int x, int y) { return key(x) < key(y); });
+      const int l = build(first, mid - first);
+      const int r = build(mid, first + count - mid);
+      S.inst_bvh[me].left = l; S.inst_bvh[me].right = r; S.inst_bvh[me].count = 0;
+    }
+    return me;
+  };
+  build(0, (int)S.inst_order.size());
+}
+float inst_box_entry(const Ray& ray, const float* b, bool& hit) {
+  float t1 = (b[0] - ray.p.x) * ray.inv.x, t2 = (b[3] - ray.p.x) * ray.inv.x;
+  float t3 = (b[1] - ray.p.y) * ray.inv.y, t4 = (b[4] - ray.p.y) * ray.inv.y;
+  float t5 = (b[2] - ray.p.z) * ray.inv.z, t6 = (b[5] - ray.p.z) * ray.inv.z;
+  float tmin = FAST_MAX(FAST_MAX(FAST_MIN(t1, t2), FAST_MIN(t3, t4)), FAST_MIN(t5, t6));
+  float tmax = FAST_MIN(FAST_MIN(FAST_MAX(t1, t2), FAST_MAX(t3, t4)), FAST_MAX(t5, t6));
+  hit = !(tmax < tmin) && !(tmax < 0.0f);   // (NaN slabs count as hits: nothing is skipped on them)
+  return tmin;
+}
+bool traverse_accel(const orc_scene& S, const Ray& ray, Hit& hitInfo, int hitSide, Counters* cnt) {
+  bool hit = false;
+  int stack[64], sp = 0, cur = 0;
+  for (;;) {
+    const orc_scene::InstNode& nd = S.inst_bvh[cur];
+    if (nd.count > 0) {
+      for (int k = nd.first; k < nd.first + nd.count; k++) {
+        const int node = S.inst_order[k];
+        bool hb;
+        const float te = inst_box_entry(ray, &S.inst_box[(size_t)node * 6], hb);
+        if (!hb || te > hitInfo.z) continue;
+        const std::vector<int>& chain = S.inst_chain[node];
+        Ray tr = ray;
+        for (int c : chain) tr = to_node(S.d.nodes[c], tr);
+        if (cnt) cnt->inst_tests++;
+        Hit local;
+        if (object_intersect(S, S.d.nodes[node], tr, local, hitSide, cnt) && local.z < hitInfo.z) {
+          hitInfo = local;
+          hit = true;
+          for (int c = (int)chain.size() - 1; c >= 0; c--) from_node(S.d.nodes[chain[c]], hitInfo);
+          hitInfo.node = node;
+        }
+      }
+    } else {
+      bool hl, hr;
+      if (cnt) cnt->node_visits += 2;
+      const float tl = inst_box_entry(ray, S.inst_bvh[nd.left].b, hl), tr = inst_box_entry(ray, S.inst_bvh[nd.right].b, hr);
+      hl = hl && !(tl > hitInfo.z);
+      hr = hr && !(tr > hitInfo.z);
+      if (hl && hr) {
+        const bool lf = tl <= tr;
+        if (sp < 63) stack[sp++] = lf ? nd.right : nd.left;
+        cur = lf ? nd.left : nd.right;
+        continue;
+      }
+      if (hl) { cur = nd.left; continue; }
+      if (hr) { cur = nd.right; continue; }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  for (uint32_t l = 0; l < S.d.n_lights; l++) {
+    const rt_light& L = S.d.lights[l];
+    if (L.kind == RT_LIGHT_POINT && L.size > 0.0f) {
+      Hit local;
+      if (light_intersect(L, ray, local, RT_HIT_FRONT_AND_BACK) && local.z < hitInfo.z) {
+        hitInfo = local;
+        hit = true;
+        hitInfo.light = (int)l;
+      }
+    }
+  }
+  return hit;
+}
+bool traverse_shadow_accel(const orc_scene& S, const Ray& ray, float t_max, Counters* cnt) {
+  int stack[64], sp = 0, cur = 0;
+  for (;;) {
+    const orc_scene::InstNode& nd = S.inst_bvh[cur];
+    if (nd.count > 0) {
+      for (int k = nd.first; k < nd.first + nd.count; k++) {
+        const int node = S.inst_order[k];
+        bool hb;
+        const float te = inst_box_entry(ray, &S.inst_box[(size_t)node * 6], hb);
+        if (!hb || te > t_max) continue;
+        Ray tr = ray;
+        for (int c : S.inst_chain[node]) tr = to_node(S.d.nodes[c], tr);
+        if (cnt) cnt->inst_tests++;
+        if (object_shadow(S, S.d.nodes[node], tr, t_max, cnt)) return true;
+      }
+    } else {
+      bool hl, hr;
+      if (cnt) cnt->node_visits += 2;
+      const float tl = inst_box_entry(ray, S.inst_bvh[nd.left].b, hl), tr = inst_box_entry(ray, S.inst_bvh[nd.right].b, hr);
+      hl = hl && !(tl > t_max);
+      hr = hr && !(tr > t_max);
+      if (hl && hr) { if (sp < 63) stack[sp++] = nd.right; cur = nd.left; continue; }
+      if (hl) { cur = nd.left; continue; }
+      if (hr) { cur = nd.right; continue; }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return false;
+}
+// Renderer::TraceRay / TraceShadowRay (RayTracer.cpp:336-344): the scene-graph walk from the root
+bool trace_scene(const orc_scene& S, const Ray& ray, Hit& hit, int hitSide, Counters* cnt) {
+  if (S.accel && !S.inst_bvh.empty()) return traverse_accel(S, ray, hit, hitSide, cnt);
+  return traverse(S, ray, 0, hit, hitSide, cnt);
+}
+bool trace_scene_shadow(const orc_scene& S, const Ray& ray, float t_max, Counters* cnt) {
+  if (S.accel && !S.inst_bvh.empty()) return traverse_shadow_accel(S, ray, t_max, cnt);
+  return traverse_shadow(S, ray, 0, t_max, cnt);
+}
+
 // ---------------------------------------------------------------- textures (texture.cpp, scene.h restated)
 
 V tile_clamp(V uvw) {  // scene.h:312-322
@@ -1101,7 +1279,7 @@ Color trace_secondary(const ShadeCtx& info, const Ray& ray, float& dist, bool re
     }
   }
   if (info.cnt) info.cnt->rays_secondary++;
-  if (traverse(S, ray, 0, hit, RT_HIT_FRONT_AND_BACK, info.cnt)) {
+  if (trace_scene(S, ray, hit, RT_HIT_FRONT_AND_BACK, info.cnt)) {
     if (hit.light < 0) {
       ShadeCtx si = info;
       si.set_hit(ray, hit);
@@ -1149,7 +1327,7 @@ Color sample_indirect_cosine(const ShadeCtx& info) {
 
 float trace_shadow(const ShadeCtx& info, const Ray& ray, float t_max) {  // lights.cpp:122-125
   if (info.cnt) info.cnt->rays_shadow++;
-  return traverse_shadow(*info.S, ray, 0, t_max, info.cnt) ? 0.0f : 1.0f;
+  return trace_scene_shadow(*info.S, ray, t_max, info.cnt) ? 0.0f : 1.0f;
 }
 
 // PointLight::Illuminate — lights.cpp:19-72
@@ -1375,7 +1553,7 @@ Color send_ray(const orc_scene& S, const rt_render_params& P, int i, const Ray& 
                const Sampler& smp, Counters* cnt, Hit* primary_out) {
   Hit hit;
   if (cnt) { cnt->rays_primary++; cnt->paths++; }
-  bool ok = traverse(S, ray, 0, hit, RT_HIT_FRONT, cnt);
+  bool ok = trace_scene(S, ray, hit, RT_HIT_FRONT, cnt);
   if (primary_out) {
     *primary_out = hit;
     primary_out->aov_depth = ok ? hit.z * length(ray.dir) : BIGFLOAT;
@@ -1544,7 +1722,7 @@ void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, con
   for (int bounce = 0; bounce < max_b; bounce++) {
     Hit h;
     if (cnt) cnt->rays_photon++;
-    if (!traverse(S, ray, 0, h, RT_HIT_FRONT, cnt)) return;
+    if (!trace_scene(S, ray, h, RT_HIT_FRONT, cnt)) return;
     if (h.node < 0) return;  // a renderable light was hit: hInfo.node is null (RayTracer.cpp:299)
     const rt_material& M = node_material(S, h.node);
     if (M.kind != RT_MTL_BLINN) return;  // MtlPhong/MtlMicrofacet::GenerateSample return false
@@ -1719,18 +1897,21 @@ void orc_trace_closest(const orc_scene* s, const rt_ray* rays, size_t n, int hit
   for (size_t i = 0; i < n; i++) {
     Ray r(from3(rays[i].p), from3(rays[i].dir));
     Hit h;
-    bool ok = traverse(*s, r, 0, h, hit_side, nullptr);
+    bool ok = trace_scene(*s, r, h, hit_side, nullptr);
     hit_to_c(h, ok, &hits[i]);
   }
 }
 void orc_trace_any(const orc_scene* s, const rt_ray* rays, const float* t_max, size_t n, uint8_t* occluded) {
   for (size_t i = 0; i < n; i++) {
     Ray r(from3(rays[i].p), from3(rays[i].dir));
-    occluded[i] = traverse_shadow(*s, r, 0, t_max ? t_max[i] : BIGFLOAT, nullptr) ? 1 : 0;
+    occluded[i] = trace_scene_shadow(*s, r, t_max ? t_max[i] : BIGFLOAT, nullptr) ? 1 : 0;
   }
 }
 
-void orc_set_accel(orc_scene* s, int on) { s->accel = on != 0; }
+void orc_set_accel(orc_scene* s, int on) {
+  s->accel = on != 0;
+  if (s->accel && s->inst_bvh.empty()) build_inst_bvh(*s);
+}
 
 int orc_photons_build(orc_scene* s, const rt_render_params* params, rt_counters* counters) {
   Counters c;

@@ -25,8 +25,10 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const rt_scene_desc* desc);
 void orc_scene_destroy(orc_scene* s);
 
-/* 1: the mesh BVHs are walked front to back with pruning (a CPU renderer with the GPU's traversal strategy) — for the second
- * cpu_baseline row of bench.py ONLY; parity checks always run with 0, the reference's visit-everything recursion. */
+/* 1: the mesh BVHs are walked front to back with pruning AND the primitive nodes sit in a BVH over their world boxes, walked
+ * the same way, in place of TraverseTree's test of every node (a CPU renderer with the GPU's data structures: SURVEY 8d's
+ * second row) — for the second cpu_baseline row of bench.py ONLY; parity checks always run with 0, the reference's
+ * visit-everything recursion.  Equal-t ties between instances may resolve differently with 1. */
 void orc_set_accel(orc_scene* s, int on);
 
 /* Renderer::TraceRay / TraceShadowRay restated (RayTracer.cpp:336-435). */
