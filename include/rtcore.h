@@ -103,7 +103,21 @@ typedef struct rt_texmap {
 
 typedef struct rt_image { const uint8_t* rgb; int32_t width, height; } rt_image; /* RGB8, row 0 first */
 
-enum { RT_MTL_BLINN = 1, RT_MTL_WHITE = 2 /* MtlPhong / MtlMicrofacet stubs return white, materials.cpp:392-408 */ };
+/* Material kinds.  The reference's MtlPhong::Shade and MtlMicrofacet::Shade return white and their GenerateSample absorbs
+ * (stubs, materials.cpp:392-408); that is what every kind other than RT_MTL_BLINN renders as by default.  With
+ * RT_EXT_MATERIALS set in rt_render_params.extensions, RT_MTL_PHONG and RT_MTL_MICROFACET are shaded by this build's own
+ * models (no counterpart in the reference; the oracle restates them):
+ *   RT_MTL_PHONG       MtlBlinn::Shade with the Phong lobe, ks (alpha + 2) / (2 pi) max(R.V, 0)^alpha, R = the light's mirror
+ *                      direction, in place of the half-vector lobe; everything else as MtlBlinn.
+ *   RT_MTL_MICROFACET  GGX / Smith / Schlick with the metallic workflow of MtlMicrofacet's parameters (materials.h:115-121),
+ *                      stored in the rt_material slots:  diffuse = color (base colour), glossiness = roughness,
+ *                      specular.value[0] (+ map) = metallic, refraction = transmittance, emission, absorption, ior. */
+enum { RT_MTL_BLINN = 1, RT_MTL_WHITE = 2, RT_MTL_PHONG = 3, RT_MTL_MICROFACET = 4 };
+/* rt_render_params.extensions (0 = the reference's behaviour) */
+#define RT_EXT_MATERIALS 1u   /* real MtlPhong / MtlMicrofacet (above) */
+#define RT_EXT_TEX_FILTER 2u  /* camera rays carry ray differentials into HitInfo::duvw and textures are evaluated with the
+                               * reference's filtered lookup Texture::Eval(uvw, duvw) (scene.h:289-303: 32 Halton-placed
+                               * lookups over the pixel's footprint); the reference never fills duvw (it stays 0) */
 /* MtlBasePhongBlinn fields (RayTracer/materials.h:52-60) */
 typedef struct rt_material {
   int32_t kind;
@@ -194,7 +208,7 @@ typedef struct rt_render_params {
   int32_t photon_max_bounces; /* cap on the photon random walk (the reference has none, RayTracer.cpp:325); 0 = 64 */
   int32_t frame_mem_mb;       /* device memory the stage queues of one pass may take, MiB; 0 = 32 GB.  Larger passes
                                  amortise kernel tails; a host with less free HBM lowers it. */
-  int32_t reserved;
+  uint32_t extensions;        /* RT_EXT_* bits: capabilities beyond the reference; 0 = off */
 } rt_render_params;
 
 /* Output images.  Any pointer may be NULL.  Host memory unless `on_device` != 0. */

@@ -1200,11 +1200,15 @@ struct ShadeCtx {  // ShadowInfo (shadowInfo.h:4-29) + SamplerInfo/ShadeInfo sta
 };
 
 Color shade(const ShadeCtx& info);
+Color shade_microfacet(const ShadeCtx& info, const rt_material& M);
 
 // Glossy half-vector shared by ReflectRay / RefractRay (materials.cpp:35-49, 79-94)
-V gloss_half_vector(const ShadeCtx& info, float glossiness, float offsetPhi, float offsetTheta, bool renorm) {
+// ggx_a2 >= 0 (RT_MTL_MICROFACET under RT_EXT_MATERIALS, this build's own model): the polar angle follows the GGX
+// distribution of squared roughness ggx_a2, cos^2 = (1 - u) / (1 + (a2 - 1) u), instead of the Blinn power lobe.
+V gloss_half_vector(const ShadeCtx& info, float glossiness, float offsetPhi, float offsetTheta, bool renorm, float ggx_a2 = -1.0f) {
   float phi = (float)(2.0f * M_PI * fmodf(halton(info.psample, 2) + offsetPhi, 1.0f));
-  float cosTheta = powf(fmodf(halton(info.psample, 3) + offsetTheta, 1.0f), 1.0f / (glossiness + 1.0f));
+  float uTheta = fmodf(halton(info.psample, 3) + offsetTheta, 1.0f);
+  float cosTheta = ggx_a2 >= 0.0f ? sqrtf((1.0f - uTheta) / (1.0f + (ggx_a2 - 1.0f) * uTheta)) : powf(uTheta, 1.0f / (glossiness + 1.0f));
   float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
   float x = sinTheta * cosf(phi);
   float y = sinTheta * sinf(phi);
@@ -1217,11 +1221,11 @@ V gloss_half_vector(const ShadeCtx& info, float glossiness, float offsetPhi, flo
 }
 
 // ReflectRay — materials.cpp:30-59.  (block, lane0) select the Philox slots for its two draws.
-Ray reflect_ray(const ShadeCtx& info, float glossiness, uint32_t block, int lane0) {
+Ray reflect_ray(const ShadeCtx& info, float glossiness, uint32_t block, int lane0, float ggx_a2 = -1.0f) {
   V view = info.Vv();
   float offsetPhi = draw(*info.smp, info.nid, block, lane0);
   float offsetTheta = draw(*info.smp, info.nid, block, lane0 + 1);
-  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, false);
+  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, false, ggx_a2);
   float d = dot(H, view);
   V dir = (2 * d) * H - view;
   dir = normalized(dir);
@@ -1229,12 +1233,12 @@ Ray reflect_ray(const ShadeCtx& info, float glossiness, uint32_t block, int lane
 }
 
 // RefractRay — materials.cpp:70-133
-Ray refract_ray(float ior, const ShadeCtx& info, float glossiness) {
+Ray refract_ray(float ior, const ShadeCtx& info, float glossiness, float ggx_a2 = -1.0f) {
   V view = info.Vv();
   float eps = 1e-4f;
   float offsetPhi = draw(*info.smp, info.nid, 0, 0);
   float offsetTheta = draw(*info.smp, info.nid, 0, 1);
-  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, true);
+  V H = gloss_half_vector(info, glossiness, offsetPhi, offsetTheta, true, ggx_a2);
   Ray refract;
   if (info.h.front) {
     float eta = 1 / ior;
@@ -1252,7 +1256,7 @@ Ray refract_ray(float ior, const ShadeCtx& info, float glossiness) {
     float NdotV = dot(view, Hb);
     float etaSq = eta * eta;
     float cosThetaSquared = (float)(1.0 - etaSq * (1 - NdotV * NdotV));
-    if (cosThetaSquared < 0.0f) return reflect_ray(info, glossiness, 1, 0);  // total internal reflection
+    if (cosThetaSquared < 0.0f) return reflect_ray(info, glossiness, 1, 0, ggx_a2);  // total internal reflection
     float cosThetaT = sqrtf(cosThetaSquared);
     V dir = -eta * view - (cosThetaT - eta * NdotV) * Hb;
     refract = Ray(info.Pp(), normalized(dir));
@@ -1379,11 +1383,127 @@ Color point_illuminate(const ShadeCtx& info, const rt_light& L, uint32_t light_i
 }
 
 // MtlBlinn::Shade — materials.cpp:222-331
+// ---- RT_MTL_MICROFACET under RT_EXT_MATERIALS: this build's own model (the reference's MtlMicrofacet::Shade is a stub,
+// materials.cpp:396-399; its parameters are MtlMicrofacet's, materials.h:115-121).  GGX distribution, separable Smith
+// masking, Schlick Fresnel, metallic workflow; the recursion's structure is MtlBlinn::Shade's (refraction child, reflection
+// child, light loop, indirect term, emission), so the device's unrolling into weighted child rays carries over.
+struct MicrofacetParams {
+  Color kd, F0, kt, emission;
+  float a2;
+};
+float ggx_g1(float x, float a2) { return (2.0f * x) / (x + sqrtf(a2 + (1.0f - a2) * (x * x))); }
+Color schlick(Color F0, float c) {
+  float m = 1.0f - c;
+  float m2 = m * m;
+  float m5 = (m2 * m2) * m;
+  return F0 + (Color(1, 1, 1) - F0) * m5;
+}
+MicrofacetParams microfacet_params(Color base, float rough, float metal, Color trans, Color emission, float ior) {
+  MicrofacetParams q;
+  metal = std::min(std::max(metal, 0.0f), 1.0f);
+  float a = rough * rough;
+  if (a < 1e-3f) a = 1e-3f;
+  q.a2 = a * a;
+  float r = (1.0f - ior) / (1.0f + ior);
+  float f0d = r * r;
+  q.F0 = Color(f0d, f0d, f0d) * (1.0f - metal) + base * metal;
+  q.kt = trans * (1.0f - metal);
+  q.kd = (base * (1.0f - metal)) * (Color(1, 1, 1) - trans);
+  q.emission = emission;
+  return q;
+}
+Color shade_microfacet(const ShadeCtx& info, const rt_material& M) {
+  const orc_scene& S = *info.S;
+  V uvw = info.h.uvw;
+  Color trans = eval_tex_color(S, M.refraction, uvw, info.cnt);
+  Color base = eval_tex_color(S, M.diffuse, uvw, info.cnt);
+  float metal = eval_tex_color(S, M.specular, uvw, info.cnt).x;
+  float rough = eval_tex_float(S, M.glossiness, uvw, info.cnt);
+  Color emission = eval_tex_color(S, M.emission, uvw, info.cnt);
+  const MicrofacetParams q = microfacet_params(base, rough, metal, trans, emission, M.ior);
+  const float a2 = q.a2;
+  const V N = info.Nn(), Vw = info.Vv();
+  const float NdotV = dot(N, Vw);
+  Color absorption = from3(M.absorption);
+  auto nonzero = [](Color c) { return c.x != 0 || c.y != 0 || c.z != 0; };
+  auto absorb = [&](Color c, float dist) {
+    if (dist > 0.0f && (absorption.x > 0.0f || absorption.y > 0.0f || absorption.z > 0.0f)) {
+      c.x *= expf(-absorption.x * dist);
+      c.y *= expf(-absorption.y * dist);
+      c.z *= expf(-absorption.z * dist);
+    }
+    return c;
+  };
+  Color finalColor(0, 0, 0), reflectCol(0, 0, 0), refractCol(0, 0, 0), indirect(0, 0, 0);
+  if (M.ior > 0.0f && info.can_bounce() && nonzero(q.kt)) {   // transmission through a GGX-sampled facet; Fresnel at the macro normal
+    Color weight = q.kt * (Color(1, 1, 1) - schlick(q.F0, fabsf(NdotV)));
+    if (nonzero(weight)) {
+      float dist;
+      Ray refract = refract_ray(M.ior, info, 0.0f, a2);
+      Color c = trace_secondary(info, refract, dist, false, 1);
+      refractCol = weight * absorb(c, dist);
+    }
+  }
+  if (info.can_bounce() && NdotV > 0.0f) {   // reflection about a GGX-sampled facet, weighted F G (V.H) / ((N.V) (N.H))
+    float oPhi = draw(*info.smp, info.nid, 0, 2), oTheta = draw(*info.smp, info.nid, 0, 3);
+    V H = gloss_half_vector(info, 0.0f, oPhi, oTheta, false, a2);
+    float VdotH = dot(Vw, H);
+    V dir = normalized((2 * VdotH) * H - Vw);
+    float NdotL = dot(N, dir), NdotH = dot(N, H);
+    if (VdotH > 0.0f && NdotL > 0.0f && NdotH > 0.0f) {
+      Color weight = schlick(q.F0, VdotH) * (((ggx_g1(NdotL, a2) * ggx_g1(NdotV, a2)) * VdotH) / (NdotV * NdotH));
+      if (nonzero(weight)) {
+        float dist;
+        Color c = trace_secondary(info, Ray(info.Pp(), dir), dist, false, 2);
+        reflectCol = weight * absorb(c, dist);
+      }
+    }
+  }
+  for (uint32_t i = 0; i < S.d.n_lights; i++) {
+    const rt_light& L = S.d.lights[i];
+    V lightDir;
+    Color lightIntensity;
+    if (L.kind == RT_LIGHT_AMBIENT) continue;
+    if (L.kind == RT_LIGHT_DIRECT) {
+      lightDir = -from3(L.direction);
+      lightIntensity = from3(L.intensity) * trace_shadow(info, Ray(info.Pp(), lightDir), BIGFLOAT);
+    } else {
+      lightIntensity = point_illuminate(info, L, i, lightDir);
+    }
+    float NdotL = dot(lightDir, N);
+    Color term = q.kd * ((float)(1 / M_PI) * std::max(NdotL, 0.0f));
+    if (NdotL > 0.0f && NdotV > 0.0f) {
+      V h = normalized(lightDir + Vw);
+      float NdotH = std::max(dot(N, h), 0.0f), VdotH = std::max(dot(Vw, h), 0.0f);
+      float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+      float D = a2 / ((float)M_PI * (dd * dd));
+      term = term + schlick(q.F0, VdotH) * (((D * ggx_g1(NdotL, a2)) * ggx_g1(NdotV, a2)) / (4.0f * NdotV));
+    }
+    finalColor = finalColor + lightIntensity * term;
+  }
+  if (info.P->mc_bounces > 0 && info.can_mc()) {
+    indirect = indirect + sample_indirect_cosine(info) * q.kd;
+  } else if (info.P->photons) {
+    const bool sec = info.secondary;
+    Color irr = (sec ? S.cmap : S.pmap).estimate(info.Pp(), N, info.P->photon_radius, sec ? info.P->ellipticity_caustic : info.P->ellipticity_global,
+                                                 info.P->photon_k, info.cnt);
+    indirect = indirect + (float)(1.0f / M_PI) * q.kd * irr;
+  }
+  finalColor = finalColor + indirect;
+  finalColor = finalColor + reflectCol;
+  finalColor = finalColor + refractCol;
+  finalColor = finalColor + q.emission;
+  return finalColor;
+}
+
 Color shade(const ShadeCtx& info) {
   const orc_scene& S = *info.S;
   if (info.cnt) info.cnt->shades++;
   const rt_material& M = node_material(S, info.h.node);
-  if (M.kind != RT_MTL_BLINN) return Color(1.0f, 1.0f, 1.0f);  // materials.cpp:396-408
+  const bool ext = (info.P->extensions & RT_EXT_MATERIALS) != 0;
+  if (ext && M.kind == RT_MTL_MICROFACET) return shade_microfacet(info, M);
+  const bool phong = ext && M.kind == RT_MTL_PHONG;
+  if (M.kind != RT_MTL_BLINN && !phong) return Color(1.0f, 1.0f, 1.0f);  // materials.cpp:396-408
   Color finalColor(0, 0, 0), ambientLight(0, 0, 0), reflectCol(0, 0, 0), refractCol(0, 0, 0), indirect(0, 0, 0);
   V uvw = info.h.uvw;
   Color reflection = eval_tex_color(S, M.reflection, uvw, info.cnt);
@@ -1395,6 +1515,7 @@ Color shade(const ShadeCtx& info) {
 
   float diffScalar = (float)(1 / M_PI);
   float specScalar = (float)((alpha + 2) / (8 * M_PI));
+  if (phong) specScalar = (float)((alpha + 2) / (2 * M_PI));   // the Phong lobe's normalisation (this build's model)
   Color cKd = kd * diffScalar;
   Color cKs = ks * specScalar;
   Color fullReflection = reflection;
@@ -1458,6 +1579,10 @@ Color shade(const ShadeCtx& info) {
     V h = normalized(lightDir + info.Vv());
     float cosphi = std::max(dot(info.Nn(), h), 0.0f);
     float costheta = std::max(dot(lightDir, info.Nn()), 0.0f);
+    if (phong) {  // R = the light direction mirrored about N; the lobe is around R . V
+      V R = (2 * dot(info.Nn(), lightDir)) * info.Nn() - lightDir;
+      cosphi = std::max(dot(R, info.Vv()), 0.0f);
+    }
     finalColor = finalColor + (lightIntensity * ((costheta * cKd) + (cKs * powf(cosphi, alpha))));
   }
 
@@ -1725,7 +1850,9 @@ void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, con
     if (!trace_scene(S, ray, h, RT_HIT_FRONT, cnt)) return;
     if (h.node < 0) return;  // a renderable light was hit: hInfo.node is null (RayTracer.cpp:299)
     const rt_material& M = node_material(S, h.node);
-    if (M.kind != RT_MTL_BLINN) return;  // MtlPhong/MtlMicrofacet::GenerateSample return false
+    const bool ext = (P.extensions & RT_EXT_MATERIALS) != 0;
+    const bool micro = ext && M.kind == RT_MTL_MICROFACET;
+    if (M.kind != RT_MTL_BLINN && !(ext && M.kind == RT_MTL_PHONG) && !micro) return;  // MtlPhong/MtlMicrofacet::GenerateSample return false
     // SamplerInfo over the photon's own stream; pSample = 0 (renderer.h:160)
     Sampler smp;
     smp.mode = RT_SAMPLER_PHILOX;
@@ -1737,6 +1864,12 @@ void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, con
     // draws for this bounce come from the photon stream, not from draw(): re-route via lambdas
     float random = rng.get((uint32_t)bounce, 0, 0);
     Color kdv = from3(M.diffuse.value), ksv = from3(M.specular.value), rfv = from3(M.refraction.value);
+    float ggx_a2 = -1.0f;
+    if (micro) {  // this build's model: the lobes' albedos from the untextured parameters, facets GGX-distributed
+      const MicrofacetParams q = microfacet_params(from3(M.diffuse.value), M.glossiness.value, M.specular.value[0], from3(M.refraction.value),
+                                                   Color(0, 0, 0), M.ior);
+      kdv = q.kd; ksv = q.F0; rfv = q.kt; ggx_a2 = q.a2;
+    }
     auto gray = [](Color q) { return (q.x + q.y + q.z) / 3.0f; };
     float diffuseProb = gray(kdv), reflectProb = gray(ksv), refractProb = gray(rfv);
     V newDir;
@@ -1750,7 +1883,7 @@ void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, con
             rng.get((uint32_t)bounce, 1, 3)};
     auto photon_reflect = [&](float oPhi, float oTheta) {
       V view = si.Vv();
-      V H = gloss_half_vector(si, M.glossiness.value, oPhi, oTheta, false);
+      V H = gloss_half_vector(si, M.glossiness.value, oPhi, oTheta, false, ggx_a2);
       float d = dot(H, view);
       return normalized((2 * d) * H - view);
     };
@@ -1775,7 +1908,7 @@ void trace_photon(orc_scene& S, const rt_render_params& P, Ray ray, Color c, con
     } else if (random < diffuseProb + reflectProb + refractProb) {
       // RefractRay with the photon stream's offsets (materials.cpp:70-133); only the direction is used (:380)
       V view = si.Vv();
-      V H = gloss_half_vector(si, M.glossiness.value, pd.phi, pd.theta, true);
+      V H = gloss_half_vector(si, M.glossiness.value, pd.phi, pd.theta, true, ggx_a2);
       if (si.h.front) {
         float eta = 1 / M.ior;
         float etaSq = eta * eta;

@@ -13,6 +13,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 RT_OK = 0
 RT_HIT_FRONT, RT_HIT_BACK, RT_HIT_FRONT_AND_BACK = 1, 2, 3
 RT_PRIM_NONE, RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_MESH = 0, 1, 2, 3
+RT_MTL_BLINN, RT_MTL_WHITE, RT_MTL_PHONG, RT_MTL_MICROFACET = 1, 2, 3, 4
+RT_EXT_MATERIALS, RT_EXT_TEX_FILTER = 1, 2   # rt_render_params.extensions
 RT_SAMPLER_PHILOX, RT_SAMPLER_PCG_HALTON = 0, 1
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECT, RT_LIGHT_POINT = 1, 2, 3
 RT_K_NAMES = ["raygen", "trace_closest", "shade", "shadow", "accum", "photon_trace", "photon_gather", "denoise", "trace_mesh",
@@ -103,7 +105,7 @@ class rt_render_params(C.Structure):
                 ("n_photons", C.c_int32), ("photon_radius", C.c_float), ("photon_k", C.c_int32),
                 ("ellipticity_global", C.c_float), ("ellipticity_caustic", C.c_float), ("skip_zero_weight", C.c_int32),
                 ("tile_begin", C.c_int32), ("tile_count", C.c_int32), ("tile_stride", C.c_int32),
-                ("photon_emit_limit", C.c_int32), ("photon_max_bounces", C.c_int32), ("frame_mem_mb", C.c_int32), ("reserved", C.c_int32)]
+                ("photon_emit_limit", C.c_int32), ("photon_max_bounces", C.c_int32), ("frame_mem_mb", C.c_int32), ("extensions", C.c_uint32)]
 
 
 class rt_framebuffer(C.Structure):

@@ -224,10 +224,33 @@ rt_material default_blinn() {  // MtlBasePhongBlinn defaults (materials.h:53-60)
 void load_material(rth_scene& s, const XmlElem* e) {
   const char* type = e->attr("type");
   rt_material m = default_blinn();
+  const char* name = e->attr("name");
   if (XmlElem::ieq(type, "blinn")) {
     m.kind = RT_MTL_BLINN;
-  } else if (XmlElem::ieq(type, "phong") || XmlElem::ieq(type, "microfacet")) {
-    m.kind = RT_MTL_WHITE;  // Shade() returns white in the reference (materials.cpp:392-408)
+  } else if (XmlElem::ieq(type, "phong")) {
+    // Shade() returns white in the reference (materials.cpp:404-408) and so does the core by default; the parameters are
+    // MtlBasePhongBlinn's and are kept for RT_EXT_MATERIALS
+    m.kind = RT_MTL_PHONG;
+  } else if (XmlElem::ieq(type, "microfacet")) {
+    // MtlMicrofacet::Load (xmlload.cpp:281-290) into the slots include/rtcore.h names: color -> diffuse, roughness ->
+    // glossiness, metallic -> specular.value[0] (+ map), transmittance -> refraction; defaults materials.h:115-121.
+    // White by default as in the reference (materials.cpp:396-399); shaded under RT_EXT_MATERIALS.
+    m.kind = RT_MTL_MICROFACET;
+    m.glossiness = {1.0f, -1};
+    m.specular = {{0, 0, 0}, -1};
+    read_textured_color(s, e->child("color"), m.diffuse);
+    read_textured_float(s, e->child("roughness"), m.glossiness);
+    rt_tex_float metallic = {0.0f, -1};
+    read_textured_float(s, e->child("metallic"), metallic);
+    m.specular.value[0] = m.specular.value[1] = m.specular.value[2] = metallic.value;
+    m.specular.map = metallic.map;
+    read_textured_color(s, e->child("emission"), m.emission);
+    read_textured_color(s, e->child("transmittance"), m.refraction);
+    read_float(e->child("ior"), m.ior);
+    if (const XmlElem* a = e->child("absorption")) read_color(a, m.absorption);
+    s.materials.push_back(m);
+    s.material_names.push_back(name ? name : "");
+    return;
   } else {
     warn(s, "unknown material type %s", type ? type : "(null)");
     return;
@@ -240,7 +263,6 @@ void load_material(rth_scene& s, const XmlElem* e) {
   read_textured_color(s, e->child("refraction"), m.refraction);
   read_float(e->child("refraction"), m.ior, "index");
   if (const XmlElem* a = e->child("absorption")) read_color(a, m.absorption);
-  const char* name = e->attr("name");
   s.materials.push_back(m);
   s.material_names.push_back(name ? name : "");
 }

@@ -15,6 +15,7 @@
 // unrolled into per-ray weights; absorption is applied when the child's hit distance is known.
 #pragma once
 #include "rt_device.h"
+#include "rtcore.h"   // RT_MTL_*, RT_EXT_*
 
 struct RayQ {
   float4* q0;  // origin.xyz, weight.r
@@ -93,6 +94,7 @@ struct PassP {
   int32_t spp_min, spp_max, adaptive;
   float adaptive_threshold;
   int32_t discard;       // sizing pass: trace and shade, but leave the accumulator alone
+  uint32_t extensions;   // rt_render_params.extensions (RT_EXT_*)
 };
 
 struct FrameBufs {
@@ -563,10 +565,13 @@ struct ShadePt {
 RT_DEV float wrap01(float u) { return u >= 1.0f ? u - 1.0f : u; }
 
 // glossy half vector, materials.cpp:35-49 / 79-94
-RT_DEV V3 gloss_half(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta, bool renorm) {
+// ggx_a2 >= 0 (RT_MTL_MICROFACET under RT_EXT_MATERIALS, this build's own model): the polar angle follows the GGX distribution
+// of squared roughness ggx_a2 instead of the Blinn power lobe.
+RT_DEV V3 gloss_half(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta, bool renorm, float ggx_a2 = -1.0f) {
   int gi = sp.sample < S.n_gloss ? sp.sample : S.n_gloss - 1;
   float phi = two_pi_times(wrap01(S.halton[RT_HGLOSS + gi] + oPhi));
-  float cosTheta = powf(wrap01(S.halton[RT_HGLOSS + S.n_gloss + gi] + oTheta), 1.0f / (gloss + 1.0f));
+  float uTheta = wrap01(S.halton[RT_HGLOSS + S.n_gloss + gi] + oTheta);
+  float cosTheta = ggx_a2 >= 0.0f ? sqrtf((1.0f - uTheta) / (1.0f + (ggx_a2 - 1.0f) * uTheta)) : powf(uTheta, 1.0f / (gloss + 1.0f));
   float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
   float sn, cs;
   sincosf(phi, &sn, &cs);   // (one argument reduction for both)
@@ -579,17 +584,18 @@ RT_DEV V3 gloss_half(const DScene& S, const ShadePt& sp, float gloss, float oPhi
   if (renorm) H = normalized(H);
   return H;
 }
-RT_DEV V3 reflect_dir(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta) {  // materials.cpp:30-59
-  V3 H = gloss_half(S, sp, gloss, oPhi, oTheta, false);
+RT_DEV V3 reflect_dir(const DScene& S, const ShadePt& sp, float gloss, float oPhi, float oTheta, float ggx_a2 = -1.0f) {  // materials.cpp:30-59
+  V3 H = gloss_half(S, sp, gloss, oPhi, oTheta, false, ggx_a2);
   float d = dot(H, sp.V);
   V3 dir = (2 * d) * H - sp.V;
   return normalized(dir);
 }
 // RefractRay, materials.cpp:70-133.  r0 = block-0 draws, r1 = block-1 draws (used on total internal reflection).
-RT_DEV void refract_ray(const DScene& S, const ShadePt& sp, float ior, float gloss, const float* r0, const float* r1, V3& o, V3& d) {
+RT_DEV void refract_ray(const DScene& S, const ShadePt& sp, float ior, float gloss, const float* r0, const float* r1, V3& o, V3& d,
+                        float ggx_a2 = -1.0f) {
   const float eps = 1e-4f;
   V3 view = sp.V;
-  V3 H = gloss_half(S, sp, gloss, r0[0], r0[1], true);
+  V3 H = gloss_half(S, sp, gloss, r0[0], r0[1], true, ggx_a2);
   if (sp.front) {
     float eta = 1 / ior;
     float etaSq = eta * eta;
@@ -608,7 +614,7 @@ RT_DEV void refract_ray(const DScene& S, const ShadePt& sp, float ior, float glo
     float cosThetaSquared = (float)(1.0 - (double)(etaSq * (1 - NdotV * NdotV)));
     if (cosThetaSquared < 0.0f) {
       o = sp.P;
-      d = reflect_dir(S, sp, gloss, r1[0], r1[1]);
+      d = reflect_dir(S, sp, gloss, r1[0], r1[1], ggx_a2);
       return;
     }
     float cosThetaT = sqrtf(cosThetaSquared);
@@ -648,6 +654,14 @@ struct ChildRay {
   V3 o, d, w;
   uint32_t meta;
 };
+// this build's microfacet model (RT_EXT_MATERIALS; oracle: ggx_g1, schlick): separable Smith masking and Schlick's Fresnel
+RT_DEV float ggx_g1(float x, float a2) { return (2.0f * x) / (x + sqrtf(a2 + (1.0f - a2) * (x * x))); }
+RT_DEV V3 schlick_f(V3 F0, float c) {
+  float m = 1.0f - c;
+  float m2 = m * m;
+  float m5 = (m2 * m2) * m;
+  return F0 + (v3(1, 1, 1) - F0) * m5;
+}
 RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs, uint32_t slot, uint32_t pixel, uint32_t sample) {
   QN.q0[ci] = make_float4(c.o.x, c.o.y, c.o.z, c.w.x);
   QN.q1[ci] = make_float4(c.d.x, c.d.y, c.d.z, c.w.y);
@@ -670,7 +684,7 @@ RT_DEV void write_child(const RayQ& QN, uint32_t ci, const ChildRay& c, V3 mabs,
 // trace kernels themselves (k_raygen_shade, k_trace_shade) for the rays they finish: those never travel through a queue
 // between being traced and being shaded.  A re-shade entry (lights.cpp:172-183) brings its hit record in Q.h0..h2[idx]
 // instead of B.  EVERY lane of the wave must call (`valid`: this lane has a shade point).
-template <bool CNT, bool MC, bool PH>
+template <bool CNT, bool MC, bool PH, bool XM>
 RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, const RayQ& Q, uint32_t idx, const RayQ& QN, const GroupQ& GH,
                         const GroupQ& GS, const GatherQ& GQ, uint32_t oseg, bool valid, uint4 m, float4 q0, float4 q1, float4 q2, const Best& B,
                         Cnt<CNT>& cnt, uint32_t& n_shades) {
@@ -688,6 +702,7 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
   sp.front = true; sp.pixel = pixel; sp.nid = nid; sp.sample = (int)m.z;
   V3 w = v3(0, 0, 0), mabs = v3(0, 0, 0), cKd = v3(0, 0, 0), cKs = v3(0, 0, 0), kd = v3(0, 0, 0);
   float alpha = 0.0f, zs = 0.0f;
+  int smode = 0;   // 0 MtlBlinn, 1 Phong lobe, 2 microfacet (cKs = F0, alpha = squared roughness): XM variants only
   float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
   ChildRay c_refr, c_refl, c_mc;
   bool p_refr = false, p_refl = false, p_mc = false, p_gather = false, refl_below = false;
@@ -756,7 +771,12 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
       n_shades++;
       aov_z = zs; aov_n = sp.N;
       const DMaterial& M = S.sinst[inst].mtl;
-      if (M.kind != 1) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
+      // this build's own MtlPhong / MtlMicrofacet (RT_EXT_MATERIALS; compiled into the XM variants only)
+      const bool xm_on = XM && (P.extensions & RT_EXT_MATERIALS) != 0;
+      const bool micro = xm_on && M.kind == RT_MTL_MICROFACET;
+      if (xm_on && M.kind == RT_MTL_PHONG) smode = 1;
+      if (micro) smode = 2;
+      if (M.kind != 1 && smode == 0) {  // MtlPhong / MtlMicrofacet::Shade return white (materials.cpp:396-408)
         add_radiance(F, slot, w);
       } else {
         surface = true;
@@ -772,14 +792,61 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
         aov_a = kd;
         float diffScalar = (float)(1 / RT_PI_D);
         float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));
-        cKd = kd * diffScalar;
-        cKs = ks * specScalar;
-        V3 fullReflection = reflection;
+        if (XM && smode == 1) specScalar = (float)(((double)(alpha + 2)) / (2 * RT_PI_D));   // the Phong lobe's normalisation
         mabs = v3(M.absorption[0], M.absorption[1], M.absorption[2]);
         bool can_bounce = (int)bounce < P.max_bounces;
         float r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
         bool have_r0 = false, have_r1 = false;
         float mior = M.ior, mgloss = M.glossiness.v;
+        if (XM && micro) {
+          // GGX / Smith / Schlick, metallic workflow (oracle: shade_microfacet): kd = base (1 - metal) (1 - transmittance),
+          // F0 = lerp(dielectric F0 of the ior, base, metal), transmission kt = transmittance (1 - metal).  For the light loop
+          // below, cKs carries F0 and alpha the squared roughness.
+          float metal = fminf(fmaxf(ks.x, 0.0f), 1.0f);
+          float a = alpha * alpha;
+          if (a < 1e-3f) a = 1e-3f;
+          const float a2 = a * a;
+          const float rr = (1.0f - mior) / (1.0f + mior);
+          const float f0d = rr * rr;
+          const V3 F0 = v3(f0d, f0d, f0d) * (1.0f - metal) + kd * metal;
+          const V3 kt = refraction * (1.0f - metal);
+          kd = (kd * (1.0f - metal)) * (v3(1, 1, 1) - refraction);
+          cKs = F0;
+          alpha = a2;
+          const float NdotV = dot(sp.N, sp.V);
+          if (mior > 0.0f && can_bounce && nonzero(kt)) {   // transmission through a GGX-sampled facet, Fresnel at the macro normal
+            V3 wc = w * (kt * (v3(1, 1, 1) - schlick_f(F0, fabsf(NdotV))));
+            if (nonzero(wc)) {
+              shade_draws(P, sp, 0, r0); have_r0 = true;
+              shade_draws(P, sp, 1, r1); have_r1 = true;
+              refract_ray(S, sp, mior, 0.0f, r0, r1, c_refr.o, c_refr.d, a2);
+              c_refr.w = wc;
+              c_refr.meta = RT_META(nid * 4 + 1, bounce + 1, 1, 0);
+              p_refr = true;
+            }
+          }
+          if (can_bounce && NdotV > 0.0f) {   // reflection about a GGX-sampled facet: F G (V.H) / ((N.V) (N.H))
+            if (!have_r0) { shade_draws(P, sp, 0, r0); have_r0 = true; }
+            const V3 H = gloss_half(S, sp, 0.0f, r0[2], r0[3], false, a2);
+            const float VdotH = dot(sp.V, H);
+            const V3 dir = normalized((2 * VdotH) * H - sp.V);
+            const float NdotL = dot(sp.N, dir), NdotH = dot(sp.N, H);
+            if (VdotH > 0.0f && NdotL > 0.0f && NdotH > 0.0f) {
+              V3 wc = w * (schlick_f(F0, VdotH) * (((ggx_g1(NdotL, a2) * ggx_g1(NdotV, a2)) * VdotH) / (NdotV * NdotH)));
+              if (nonzero(wc)) {
+                c_refl.d = dir;
+                c_refl.o = sp.P;
+                c_refl.w = wc;
+                c_refl.meta = RT_META(nid * 4 + 2, bounce + 1, 1, 0);
+                p_refl = true;
+              }
+            }
+          }
+          cKd = kd * diffScalar;
+        } else {
+        cKd = kd * diffScalar;
+        cKs = ks * specScalar;
+        V3 fullReflection = reflection;
         if (mior > 0.0f && can_bounce && nonzero(refraction)) {  // materials.cpp:246-269
           float iorRatio = (1.0f - mior) / (1.0f + mior);
           V3 fresnel = refraction * (iorRatio * iorRatio);
@@ -805,6 +872,7 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
             c_refl.meta = RT_META(nid * 4 + 2, bounce + 1, 1, refl_below ? 1 : 0);
             p_refl = true;
           }
+        }
         }
         V3 local = emission;
         if (MC && P.mc_bounces > 0 && (int)bounce < P.mc_bounces) {  // materials.cpp:310-312 + 175-212 (mcSamples = 1)
@@ -877,9 +945,25 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
       V3 h = normalized(lightDir + sp.V);
       float cosphi = fmaxf(dot(sp.N, h), 0.0f);
       float costheta = fmaxf(dot(lightDir, sp.N), 0.0f);
+      if (XM && smode == 1) {  // Phong: the lobe is around R . V, R = the light direction mirrored about N
+        V3 R = (2 * dot(sp.N, lightDir)) * sp.N - lightDir;
+        cosphi = fmaxf(dot(R, sp.V), 0.0f);
+      }
+      if (XM && smode == 2) {  // microfacet: D G F / (4 N.V)  (the N.L of the denominator cancels the cosine)
+        const float NdotL = dot(lightDir, sp.N), NdotV = dot(sp.N, sp.V), a2 = alpha;
+        V3 term = cKd * costheta;
+        if (NdotL > 0.0f && NdotV > 0.0f) {
+          const float VdotH = fmaxf(dot(sp.V, h), 0.0f);
+          const float dd = (cosphi * cosphi) * (a2 - 1.0f) + 1.0f;
+          const float D = a2 / (RT_PI_F * (dd * dd));
+          term = term + schlick_f(cKs, VdotH) * (((D * ggx_g1(NdotL, a2)) * ggx_g1(NdotV, a2)) / (4.0f * NdotV));
+        }
+        contrib = w * (inten * term);
+      } else {
       // (0 * powf(..) is +0 for every finite power of a cosine in [0, 1]: a wave of purely diffuse points skips powf)
       const float spec = nonzero(cKs) ? powf(cosphi, alpha) : 0.0f;
       contrib = w * (inten * ((costheta * cKd) + (cKs * spec)));
+      }
       lit = nonzero(contrib);
       if (lit && soft) {
         float rl[4];
@@ -917,7 +1001,7 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
   }
 }
 
-template <bool CNT, bool MC, bool PH>
+template <bool CNT, bool MC, bool PH, bool XM>
 RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   Cnt<CNT> cnt;
   uint32_t n_shades = 0;
@@ -937,7 +1021,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
     }
     Best B;
     unpack_raw(raw0, raw_face, B);
-    shade_point<CNT, MC, PH>(S, P, F, Q, idx, QN, GH, GS, GQ, oseg, seg_valid, m, q0, q1, q2, B, cnt, n_shades);
+    shade_point<CNT, MC, PH, XM>(S, P, F, Q, idx, QN, GH, GS, GQ, oseg, seg_valid, m, q0, q1, q2, B, cnt, n_shades);
   RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);
@@ -952,7 +1036,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
 // form, for three quarters of C2's rays and all of C3's).  A ray with mesh candidates is appended to the compact queue QM
 // (entry + work item at the same index, one atomic per wave), walked by k_trace_mesh and shaded by k_shade, which then
 // sees nothing but mesh hits.  Children of both go to QN, in the parent's segment.
-template <bool CNT, bool TLAS, bool MC, bool PH>
+template <bool CNT, bool TLAS, bool MC, bool PH, bool XM>
 RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint32_t* l0_counts, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS,
             GatherQ GQ) {
   RT_STACK_DECL
@@ -990,7 +1074,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint
       it.x = wi; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
       MQ.item4[wi] = it;
     }
-    shade_point<CNT, MC, PH>(S, P, F, QM, 0u, QN, GH, GS, GQ, seg, valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
+    shade_point<CNT, MC, PH, XM>(S, P, F, QM, 0u, QN, GH, GS, GQ, seg, valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
   }
   // camera samples per segment: what the host measures the queues' fan-out against
   const uint32_t tiles = (total + 63u) / 64u;
@@ -1009,7 +1093,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint
 }
 
 // Secondary rays (level >= 1): the children k_shade / the fused kernels appended to Q.
-template <bool CNT, bool TLAS, bool MC, bool PH>
+template <bool CNT, bool TLAS, bool MC, bool PH, bool XM>
 RT_KERNEL_W(RT_SHADE_WAVES, k_trace_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
@@ -1043,7 +1127,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_trace_shade, DScene S, PassP P, FrameBufs F, RayQ 
       it.x = wi; it.y = __float_as_uint(B.t); it.z = (uint32_t)(B.inst + 1) | (B.front ? 0x80000000u : 0u); it.w = head;
       MQ.item4[wi] = it;
     }
-    shade_point<CNT, MC, PH>(S, P, F, Q, idx, QN, GH, GS, GQ, seg, seg_valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
+    shade_point<CNT, MC, PH, XM>(S, P, F, Q, idx, QN, GH, GS, GQ, seg, seg_valid && !to_mesh, m, q0, q1, q2, B, cnt, n_shades);
   RT_SEG_END
   if (CNT) {
     cnt.flush(F.counters);

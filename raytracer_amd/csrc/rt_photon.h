@@ -31,6 +31,7 @@ struct PhotonTraceP {
   uint32_t seed_lo, seed_hi;
   uint32_t first, count;   // photon paths [first, first + count)
   int32_t max_bounces;
+  int32_t ext_materials;   // RT_EXT_MATERIALS: this build's MtlPhong / MtlMicrofacet::GenerateSample (the reference's absorb)
   int32_t n_plights;
   int32_t accept[2];       // 0: that map already holds its n photons from earlier batches
   uint32_t cap;            // record capacity per map
@@ -92,7 +93,8 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
       if (!scene_closest<CNT>(S, o, d, 1, h, stk, stride, cnt)) break;
       if (h.inst < 0) break;  // a renderable light: hInfo.node is null (RayTracer.cpp:299)
       const DMaterial& M = S.materials[S.inst[h.inst].mtl];
-      if (M.kind != 1) break;  // MtlPhong / MtlMicrofacet::GenerateSample return false
+      const bool micro = PP.ext_materials && M.kind == RT_MTL_MICROFACET;
+      if (M.kind != 1 && !(PP.ext_materials && M.kind == RT_MTL_PHONG) && !micro) break;  // MtlPhong / MtlMicrofacet::GenerateSample return false
       ShadePt sp;
       sp.P = h.p;
       sp.N = normalized(h.N);
@@ -106,6 +108,19 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
       V3 kdv = v3(M.diffuse.v[0], M.diffuse.v[1], M.diffuse.v[2]);
       V3 ksv = v3(M.specular.v[0], M.specular.v[1], M.specular.v[2]);
       V3 rfv = v3(M.refraction.v[0], M.refraction.v[1], M.refraction.v[2]);
+      float ggx_a2 = -1.0f;
+      if (micro) {  // this build's model (oracle: microfacet_params): lobe albedos from the untextured parameters, GGX facets
+        const float metal = fminf(fmaxf(ksv.x, 0.0f), 1.0f);
+        float a = M.glossiness.v * M.glossiness.v;
+        if (a < 1e-3f) a = 1e-3f;
+        ggx_a2 = a * a;
+        const float rr = (1.0f - M.ior) / (1.0f + M.ior);
+        const float f0d = rr * rr;
+        ksv = v3(f0d, f0d, f0d) * (1.0f - metal) + kdv * metal;
+        const V3 tr = rfv;
+        rfv = tr * (1.0f - metal);
+        kdv = (kdv * (1.0f - metal)) * (v3(1, 1, 1) - tr);
+      }
       float diffuseProb = (kdv.x + kdv.y + kdv.z) / 3.0f;   // Color::Gray
       float reflectProb = (ksv.x + ksv.y + ksv.z) / 3.0f;
       float refractProb = (rfv.x + rfv.y + rfv.z) / 3.0f;
@@ -126,7 +141,7 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
         lobe = 1;
       } else if (random < diffuseProb + reflectProb) {
         philox4x32_10(e, (uint32_t)bounce, 1, RT_TAG_PHOTON, PP.seed_lo, PP.seed_hi, r1);
-        newDir = reflect_dir(S, sp, M.glossiness.v, u32_to_unit(r1[0]), u32_to_unit(r1[1]));
+        newDir = reflect_dir(S, sp, M.glossiness.v, u32_to_unit(r1[0]), u32_to_unit(r1[1]), ggx_a2);
         mult = ksv * dot(newDir, sp.N);
         prob = reflectProb;
         lobe = 2;
@@ -134,7 +149,7 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
         philox4x32_10(e, (uint32_t)bounce, 1, RT_TAG_PHOTON, PP.seed_lo, PP.seed_hi, r1);
         float ra[2] = {u32_to_unit(r1[0]), u32_to_unit(r1[1])}, rb[2] = {u32_to_unit(r1[2]), u32_to_unit(r1[3])};
         V3 ro;
-        refract_ray(S, sp, M.ior, M.glossiness.v, ra, rb, ro, newDir);  // only the direction is used (materials.cpp:380)
+        refract_ray(S, sp, M.ior, M.glossiness.v, ra, rb, ro, newDir, ggx_a2);  // only the direction is used (materials.cpp:380)
         mult = rfv * fabsf(dot(newDir, sp.N));
         prob = refractProb;
         lobe = 4;

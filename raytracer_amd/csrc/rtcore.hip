@@ -1323,7 +1323,7 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
   if (RP.photon_k <= 0 || RP.photon_k > RT_PHOTON_MAX_K) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_k must be in 1..256");
   long long limit = RP.photon_emit_limit > 0 ? RP.photon_emit_limit : 20ll * RP.n_photons;
   int max_b = RP.photon_max_bounces > 0 ? RP.photon_max_bounces : 64;
-  uint32_t key[8] = {RP.seed_lo, RP.seed_hi, (uint32_t)RP.n_photons, (uint32_t)limit, (uint32_t)max_b, 1u, 0u, 0u};
+  uint32_t key[8] = {RP.seed_lo, RP.seed_hi, (uint32_t)RP.n_photons, (uint32_t)limit, (uint32_t)max_b, 1u, RP.extensions & RT_EXT_MATERIALS, 0u};
   if (ps.built && !std::memcmp(key, ps.key, sizeof key)) return RT_OK;
   ps.built = false;
   const uint32_t n = (uint32_t)RP.n_photons;
@@ -1378,6 +1378,7 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
       PP.seed_lo = RP.seed_lo; PP.seed_hi = RP.seed_hi;
       PP.first = emitted; PP.count = count;
       PP.max_bounces = max_b;
+      PP.ext_materials = (RP.extensions & RT_EXT_MATERIALS) ? 1 : 0;
       PP.n_plights = (int32_t)plights.size();
       PP.accept[0] = kept[0] < n; PP.accept[1] = kept[1] < n;
       PP.cap = cap;
@@ -1768,6 +1769,19 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
   //  higher occupancy — and keep the separate kernels)
   const bool fuse = ctx->opt.fuse != 0 && !ctx->ds.use_tlas;
   const bool mc = P.mc_bounces > 0, ph = P.photons != 0;
+  const bool xm = P.extensions != 0;
+#define RT_SHADE(n_, Q_)                                                                                        \
+  do {                                                                                                          \
+    if (xm) {                                                                                                   \
+      if (mc && ph) LAUNCH((k_shade<CNT, true, true, true>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);            \
+      else if (mc) LAUNCH((k_shade<CNT, true, false, true>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);            \
+      else if (ph) LAUNCH((k_shade<CNT, false, true, true>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);            \
+      else LAUNCH((k_shade<CNT, false, false, true>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);                   \
+    } else if (mc && ph) LAUNCH((k_shade<CNT, true, true, false>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);      \
+    else if (mc) LAUNCH((k_shade<CNT, true, false, false>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);             \
+    else if (ph) LAUNCH((k_shade<CNT, false, true, false>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);             \
+    else LAUNCH((k_shade<CNT, false, false, false>), n_, ctx->ds, P, F, Q_, Qn, GH, GS, GQ);                    \
+  } while (0)
   if (!fuse) {  // camera rays + their first phase (instance table)
     MeshQ MQ = meshq(ctx->MQ, 0, CNT_MQ, CUR_MQ);
     Timer t(ctx, RT_K_RAYGEN);
@@ -1795,10 +1809,15 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       QM.counts = MQ.counts;
 #define RT_FUSED(kern, ...)                                                                                     \
       do {                                                                                                      \
-        if (mc && ph) LAUNCH_P1((kern<CNT, false, true, true>), __VA_ARGS__);                                   \
-        else if (mc) LAUNCH_P1((kern<CNT, false, true, false>), __VA_ARGS__);                                   \
-        else if (ph) LAUNCH_P1((kern<CNT, false, false, true>), __VA_ARGS__);                                   \
-        else LAUNCH_P1((kern<CNT, false, false, false>), __VA_ARGS__);                                          \
+        if (xm) {   /* RT_EXT_* variants: this build's own materials / filtered texture lookups compiled in */   \
+          if (mc && ph) LAUNCH_P1((kern<CNT, false, true, true, true>), __VA_ARGS__);                           \
+          else if (mc) LAUNCH_P1((kern<CNT, false, true, false, true>), __VA_ARGS__);                           \
+          else if (ph) LAUNCH_P1((kern<CNT, false, false, true, true>), __VA_ARGS__);                           \
+          else LAUNCH_P1((kern<CNT, false, false, false, true>), __VA_ARGS__);                                  \
+        } else if (mc && ph) LAUNCH_P1((kern<CNT, false, true, true, false>), __VA_ARGS__);                     \
+        else if (mc) LAUNCH_P1((kern<CNT, false, true, false, false>), __VA_ARGS__);                            \
+        else if (ph) LAUNCH_P1((kern<CNT, false, false, true, false>), __VA_ARGS__);                            \
+        else LAUNCH_P1((kern<CNT, false, false, false, false>), __VA_ARGS__);                                   \
       } while (0)
       if (lvl == 0) {
         Timer t(ctx, RT_K_RAYGEN);
@@ -1818,10 +1837,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
           t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
         }
         Timer t(ctx, RT_K_SHADE);
-        if (mc && ph) LAUNCH((k_shade<CNT, true, true>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
-        else if (mc) LAUNCH((k_shade<CNT, true, false>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
-        else if (ph) LAUNCH((k_shade<CNT, false, true>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
-        else LAUNCH((k_shade<CNT, false, false>), mub, ctx->ds, P, F, QM, Qn, GH, GS, GQ);
+        RT_SHADE(mub, QM);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MQ));
       }
     } else {
@@ -1841,10 +1857,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       }
       {
         Timer t(ctx, RT_K_SHADE);
-        if (mc && ph) LAUNCH((k_shade<CNT, true, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-        else if (mc) LAUNCH((k_shade<CNT, true, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-        else if (ph) LAUNCH((k_shade<CNT, false, true>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
-        else LAUNCH((k_shade<CNT, false, false>), ubn, ctx->ds, P, F, Qc, Qn, GH, GS, GQ);
+        RT_SHADE(ubn, Qc);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
       }
     }
@@ -1950,6 +1963,7 @@ int check_params(rt_context* ctx, const rt_render_params& P) {
   if (P.mc_bounces > 0 && P.mc_samples != 1) return fail(ctx, RT_ERR_UNSUPPORTED, "mc_samples must be 1 (renderer.h:172)");
   if (P.shadow_min <= 0 || P.shadow_max < P.shadow_min) return fail(ctx, RT_ERR_INVALID, "bad shadow_min/shadow_max");
   if (P.sample_begin < 0 || P.sample_count < 0 || P.sample_begin + P.sample_count > 65536) return fail(ctx, RT_ERR_INVALID, "bad sample range");
+  if (P.extensions & ~(RT_EXT_MATERIALS | RT_EXT_TEX_FILTER)) return fail(ctx, RT_ERR_INVALID, "unknown bits in extensions");
   return RT_OK;
 }
 
@@ -2005,7 +2019,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   };
   size_t fkey[10] = {(size_t)W, (size_t)H, (size_t)RP.max_bounces, (size_t)RP.mc_bounces, (size_t)RP.pixel_jitter, (size_t)n_hard,
                      (size_t)n_soft, (size_t)photons_mixed, (size_t)(RP.skip_zero_weight != 0) + 2 * (size_t)RP.shadow_min + 512 * (size_t)RP.shadow_max,
-                     (size_t)RP.tile_stride};
+                     (size_t)RP.tile_stride + ((size_t)RP.extensions << 32)};
   if (ctx->fan_valid && std::memcmp(fkey, ctx->fan_key, sizeof fkey)) ctx->fan_valid = false;
   const bool need_pilot = !ctx->fan_valid && worst > 1.0;
   if (!need_pilot && !ctx->fan_valid) {  // no secondary rays at all: the worst case is exact
@@ -2061,6 +2075,7 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   P.aov_sample = begin;
   P.spp_min = RP.spp_min; P.spp_max = RP.spp_max; P.adaptive = adaptive ? 1 : 0;
   P.adaptive_threshold = RP.adaptive_threshold;
+  P.extensions = RP.extensions;
 
   FrameBufs F;
   F.path_rad = ctx->d_path_rad;

@@ -196,6 +196,64 @@ def check_boundary_extras(r):
     assert lib.rt_context_create_multi(0, None, out) != 0 and lib.rt_context_create_multi(1, None, None) != 0
 
 
+def check_extended_materials(r, w=160, h=90, spp=4, photons=True):
+    """SURVEY 8f n4, RT_EXT_MATERIALS: this build's own MtlPhong / MtlMicrofacet (the reference's are stubs that return white,
+    materials.cpp:392-408) against their restatement in the oracle.  Without the extension both sides render the reference's
+    white; with it: deterministic frame ids exact and colour within 1e-4 relative, stochastic frame (reflection + transmission
+    children, soft shadows) within the stochastic gate, photon deposits on microfacet surfaces gathered alike."""
+    import oracle_ffi
+    from conftest import scene_path
+    from raytracer_amd import Scene
+    from raytracer_amd._ffi import RT_EXT_MATERIALS, RT_MTL_MICROFACET, RT_MTL_PHONG
+    scene = Scene.load(scene_path("ext_materials.xml"))
+    kinds = [scene.desc.materials[i].kind for i in range(scene.desc.n_materials)]
+    assert kinds.count(RT_MTL_MICROFACET) == 4 and kinds.count(RT_MTL_PHONG) == 1
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p0 = params(w, h, spp=1, jitter=0, bounces=0)
+    g0, c0 = r.Render(p0), orc.render(p0)
+    assert np.array_equal(g0.hit_node, c0.hit_node) and rel_colour_diff(g0.radiance, c0.radiance) <= 1e-4
+    on_stub = np.isin(c0.hit_node, [i for i in range(scene.desc.n_nodes) if scene.node_name(i) in ("phong", "plastic", "gold", "glass", "floor")])
+    assert on_stub.any() and np.allclose(c0.radiance[on_stub][:, :3], 1.0), "the reference's stubs shade white"
+    p1 = params(w, h, spp=1, jitter=0, bounces=0)
+    p1.extensions = RT_EXT_MATERIALS
+    g1, c1 = r.Render(p1), orc.render(p1)
+    assert np.array_equal(g1.hit_node, c1.hit_node)
+    assert rel_colour_diff(g1.radiance, c1.radiance) <= 1e-4, rel_colour_diff(g1.radiance, c1.radiance)
+    assert np.abs(c1.radiance[on_stub][:, :3] - 1.0).mean() > 0.2, "the models replace the white stubs"
+    for name in ("phong", "plastic", "gold", "floor"):   # every model is lit and not constant over its object
+        sel = c1.hit_node == [i for i in range(scene.desc.n_nodes) if scene.node_name(i) == name][0]
+        assert sel.sum() > 50 and c1.radiance[sel][:, :3].std() > 1e-3 and c1.radiance[sel][:, :3].max() > 0.02, name
+    p2 = params(w, h, spp=spp, jitter=1, bounces=3)
+    p2.extensions = RT_EXT_MATERIALS
+    g2, (c2, cnt) = r.Render(p2), orc.render(p2, want_counters=True)
+    assert cnt["rays_secondary"] > 0.3 * cnt["rays_primary"]
+    print("extended materials", assert_stochastic_close(g2, c2, "ext materials", frac=0.999, psnr=70.0, mean=1e-5))
+    bad = params(w, h)
+    bad.extensions = 1 << 7
+    try:
+        r.Render(bad)
+        assert False, "unknown extension bits must be refused"
+    except RuntimeError:
+        pass
+    if photons:
+        import photon_checks
+        q = photon_checks.photon_params(3000, w=64, h=36, spp=2)
+        q.extensions = RT_EXT_MATERIALS
+        r.LoadScene(scene)
+        g3 = r.Render(q)
+        n_glob, n_caus = len(r.GetPhotonMap()), len(r.GetCausticsMap())
+        assert n_glob == 3000 and n_caus > 100, (n_glob, n_caus)   # microfacet surfaces take deposits, specular / transmitted paths exist
+        for which in (0, 1):
+            orc.photons_set_tree(which, r.GetPhotonTree(which))
+        c3 = orc.render(q)
+        mean = float(np.abs(g3.radiance[..., :3] - c3.radiance[..., :3]).mean())
+        assert psnr8(g3.img, c3.img) >= 60.0 and mean <= 1e-4, (psnr8(g3.img, c3.img), mean)
+        q0 = photon_checks.photon_params(3000, w=64, h=36, spp=2)
+        r.Render(q0)     # without the extension the stubs absorb every photon that reaches them (a different map)
+        assert len(r.GetCausticsMap()) < n_caus, "the stubs' GenerateSample returns false"
+
+
 def check_edge_cases(r):
     """Empty scene, scene without lights, a default-material node, ragged image sizes (partial 32x32 tiles,
     partial 64-path wave tiles), 1x1 image, empty ray batches."""

@@ -273,6 +273,10 @@ def test_instance_bvh_matches_scene_graph_walk(emu, monkeypatch):
     common_checks.check_instance_bvh(emu, monkeypatch, scene_path)
 
 
+def test_extended_materials(emu):
+    common_checks.check_extended_materials(emu, w=96, h=54, spp=2)
+
+
 def test_boundary_extras(emu):
     common_checks.check_boundary_extras(emu)
 

@@ -71,7 +71,7 @@ def test_xml_dialect_semantics():
     assert inner.kind == 1 and np.allclose(outer.color[1].value[:], [0.5] * 3)
     assert np.allclose(np.array(inner.itm.m[:])[[0, 4, 8]], [4, 4, 4])       # inverse of scale 0.25
     assert np.allclose(np.array(outer.itm.m[:])[[0, 4, 8]], [2, 2, 1])
-    assert d.materials[1].kind == 2  # phong stub shades white
+    assert d.materials[1].kind == 3  # RT_MTL_PHONG: shades white (the reference's stub) unless RT_EXT_MATERIALS is set
     assert np.allclose(d.background.value[:], [0.1, 0.2, 0.3]) and d.background.map == -1
     cam = d.camera
     assert cam.srgb == 1 and (cam.width, cam.height) == (64, 48) and cam.fov == 30
