@@ -190,6 +190,8 @@ struct Hit {  // scene.h:74-90
   int face;
   float aov_depth;  // filled for the primary hit of the AOV sample only (rt_framebuffer depth / normal / albedo)
   V aov_normal, aov_albedo;
+  V duvw[2];        // scene.h:82 — zero in the reference (never filled); RT_EXT_TEX_FILTER fills it for camera rays
+  bool filtered = false;   // ... and marks the hit for the filtered lookups
   Hit() { init(); }
   void init() {
     z = BIGFLOAT; node = -1; uvw = V(0.5f, 0.5f, 0.5f); front = true; light = -1; face = -1;
@@ -1147,6 +1149,50 @@ float eval_tex_float(const orc_scene& S, const rt_tex_float& tf, V uvw, Counters
   if (tf.map < 0) return tf.value;
   return tf.value * eval_map(S, tf.map, uvw, cnt).x;
 }
+// Texture::Eval(uvw, duvw) — scene.h:289-303 (32 lookups placed by the Halton points of bases 2 and 3 in the parallelogram
+// of the derivatives) behind TextureMap::Eval(uvw, duvw) — scene.h:338-343 — and TexturedValue::Eval(uvw, duvw) — :374.
+// The reference only ever calls it with zero derivatives (HitInfo::duvw is never filled): RT_EXT_TEX_FILTER (this build).
+Color texmap_tap(const orc_scene& S, const rt_texmap& tm, V u, Counters* cnt) {
+  if (tm.kind == RT_TEX_IMAGE) return image_eval(S.d.images[tm.image], u);
+  V t = tile_clamp(u);
+  int k = (t.x <= 0.5f) ^ (t.y <= 0.5f);
+  return eval_tex_color(S, tm.color[k], u, cnt);   // texture.cpp:139: the checker's colours are evaluated unfiltered
+}
+Color eval_tex_color_filtered(const orc_scene& S, const rt_tex_color& tc, V uvw, const V duvw[2], Counters* cnt) {
+  Color v = from3(tc.value);
+  if (tc.map < 0) return v;
+  const rt_texmap& tm = S.d.texmaps[tc.map];
+  V u = xform_point(tm.itm, uvw);
+  V d[2] = {xform_dir(tm.itm, duvw[0]), xform_dir(tm.itm, duvw[1])};   // DirectionTransformTo
+  if (cnt) cnt->tex_evals++;
+  Color c = texmap_tap(S, tm, u, cnt);
+  if (dot(d[0], d[0]) + dot(d[1], d[1]) == 0) return v * c;
+  const int sampleCount = 32;
+  for (int i = 1; i < sampleCount; i++) {
+    float x = 0, y = 0, fx = 0.5f, fy = 1.0f / 3.0f;
+    for (int ix = i; ix > 0; ix /= 2) { x += fx * (ix % 2); fx /= 2; }
+    for (int iy = i; iy > 0; iy /= 3) { y += fy * (iy % 3); fy /= 3; }
+    if (x > 0.5f) x -= 1;
+    if (y > 0.5f) y -= 1;
+    c = c + texmap_tap(S, tm, u + x * d[0] + y * d[1], cnt);
+  }
+  return v * (c / float(sampleCount));
+}
+float eval_tex_float_filtered(const orc_scene& S, const rt_tex_float& tf, V uvw, const V duvw[2], Counters* cnt) {
+  if (tf.map < 0) return tf.value;
+  rt_tex_color tc;
+  tc.value[0] = tc.value[1] = tc.value[2] = 1.0f;
+  tc.map = tf.map;
+  return tf.value * eval_tex_color_filtered(S, tc, uvw, duvw, cnt).x;
+}
+// ShadeInfo::Eval (renderer.h:135-136): every material parameter goes through Eval(uvw, duvw)
+Color eval_shade_color(const orc_scene& S, const rt_tex_color& tc, const Hit& h, Counters* cnt) {
+  return h.filtered ? eval_tex_color_filtered(S, tc, h.uvw, h.duvw, cnt) : eval_tex_color(S, tc, h.uvw, cnt);
+}
+float eval_shade_float(const orc_scene& S, const rt_tex_float& tf, const Hit& h, Counters* cnt) {
+  return h.filtered ? eval_tex_float_filtered(S, tf, h.uvw, h.duvw, cnt) : eval_tex_float(S, tf, h.uvw, cnt);
+}
+
 Color eval_environment(const orc_scene& S, const rt_tex_color& tc, V dir, Counters* cnt) {  // scene.h:377-384
   float len = length(dir);
   float z = asinf(-dir.z / len) / (float)M_PI + 0.5f;
@@ -1274,6 +1320,7 @@ Color trace_secondary(const ShadeCtx& info, const Ray& ray, float& dist, bool re
     if (dot(ray.dir, info.Nn()) < 0) {  // reflected below the surface: re-shade the same point
       ShadeCtx si = info;
       hit = info.h;
+      hit.filtered = false;   // (a secondary shade: no derivatives)
       si.set_hit(ray, hit);
       si.bounce++;
       si.secondary = true;
@@ -1414,12 +1461,11 @@ MicrofacetParams microfacet_params(Color base, float rough, float metal, Color t
 }
 Color shade_microfacet(const ShadeCtx& info, const rt_material& M) {
   const orc_scene& S = *info.S;
-  V uvw = info.h.uvw;
-  Color trans = eval_tex_color(S, M.refraction, uvw, info.cnt);
-  Color base = eval_tex_color(S, M.diffuse, uvw, info.cnt);
-  float metal = eval_tex_color(S, M.specular, uvw, info.cnt).x;
-  float rough = eval_tex_float(S, M.glossiness, uvw, info.cnt);
-  Color emission = eval_tex_color(S, M.emission, uvw, info.cnt);
+  Color trans = eval_shade_color(S, M.refraction, info.h, info.cnt);
+  Color base = eval_shade_color(S, M.diffuse, info.h, info.cnt);
+  float metal = eval_shade_color(S, M.specular, info.h, info.cnt).x;
+  float rough = eval_shade_float(S, M.glossiness, info.h, info.cnt);
+  Color emission = eval_shade_color(S, M.emission, info.h, info.cnt);
   const MicrofacetParams q = microfacet_params(base, rough, metal, trans, emission, M.ior);
   const float a2 = q.a2;
   const V N = info.Nn(), Vw = info.Vv();
@@ -1505,13 +1551,12 @@ Color shade(const ShadeCtx& info) {
   const bool phong = ext && M.kind == RT_MTL_PHONG;
   if (M.kind != RT_MTL_BLINN && !phong) return Color(1.0f, 1.0f, 1.0f);  // materials.cpp:396-408
   Color finalColor(0, 0, 0), ambientLight(0, 0, 0), reflectCol(0, 0, 0), refractCol(0, 0, 0), indirect(0, 0, 0);
-  V uvw = info.h.uvw;
-  Color reflection = eval_tex_color(S, M.reflection, uvw, info.cnt);
-  Color refraction = eval_tex_color(S, M.refraction, uvw, info.cnt);
-  Color kd = eval_tex_color(S, M.diffuse, uvw, info.cnt);
-  Color ks = eval_tex_color(S, M.specular, uvw, info.cnt);
-  float alpha = eval_tex_float(S, M.glossiness, uvw, info.cnt);
-  Color emission = eval_tex_color(S, M.emission, uvw, info.cnt);
+  Color reflection = eval_shade_color(S, M.reflection, info.h, info.cnt);
+  Color refraction = eval_shade_color(S, M.refraction, info.h, info.cnt);
+  Color kd = eval_shade_color(S, M.diffuse, info.h, info.cnt);
+  Color ks = eval_shade_color(S, M.specular, info.h, info.cnt);
+  float alpha = eval_shade_float(S, M.glossiness, info.h, info.cnt);
+  Color emission = eval_shade_color(S, M.emission, info.h, info.cnt);
 
   float diffScalar = (float)(1 / M_PI);
   float specScalar = (float)((alpha + 2) / (8 * M_PI));
@@ -1674,11 +1719,77 @@ Ray primary_ray(const orc_scene& S, const rt_render_params& P, const CamConsts& 
 }
 
 // RayTracer::SendRay — RayTracer.cpp:227-259
+// HitInfo::duvw (scene.h:82) as this build fills it under RT_EXT_TEX_FILTER (the reference leaves it zero): the texture
+// coordinates where the rays through the pixels to the right and below, from the same origin, meet the surface's local
+// approximation — in the hit node's space: the plane itself; the sphere's tangent plane at the hit, projected back onto the
+// sphere; the hit triangle's plane with its barycentric interpolation — minus the hit's own.  Only hits whose material reads
+// a texture map carry derivatives.  Mirrors hit_differentials (rt_device.h) operation for operation.
+void primary_differentials(const orc_scene& S, const rt_render_params& P, const Ray& ray, Hit& hit) {
+  const rt_material& M = node_material(S, hit.node);
+  if (!(M.diffuse.map >= 0 || M.specular.map >= 0 || M.emission.map >= 0 || M.reflection.map >= 0 || M.refraction.map >= 0 || M.glossiness.map >= 0)) return;
+  const CamConsts C = cam_consts(S, P);
+  const V dxr = ray.dir + C.X * (C.ww / C.camW), dyr = ray.dir - C.Y * (C.wh / C.camH);
+  std::vector<int> chain;
+  for (int k = hit.node; k >= 0; k = S.d.nodes[k].parent) chain.push_back(k);
+  V p = ray.p, d = ray.dir, ex = dxr, ey = dyr;
+  for (int c = (int)chain.size() - 1; c >= 0; c--) {
+    const rt_node& n = S.d.nodes[chain[c]];
+    V np = xform_point(n.itm, p), nd = xform_dir(n.itm, d), nx = xform_dir(n.itm, ex), ny = xform_dir(n.itm, ey);
+    p = np; d = nd; ex = nx; ey = ny;
+  }
+  const rt_node& node = S.d.nodes[hit.node];
+  const V uvw = hit.uvw;
+  for (int a = 0; a < 2; a++) {
+    const V e = a ? ey : ex;
+    V uv2 = uvw;
+    if (node.prim_kind == RT_PRIM_PLANE) {
+      if (!(fabsf(e.z) < 1e-8f)) {
+        const float t = -(p.z / e.z);
+        const V hp = p + e * t;
+        uv2 = V((hp.x + 1.0f) * 0.5f, (hp.y + 1.0f) * 0.5f, 0.0f);
+      }
+    } else if (node.prim_kind == RT_PRIM_SPHERE) {
+      const V hp0 = p + (d * hit.z);
+      const float den = dot(e, hp0);
+      if (!(fabsf(den) < 1e-8f)) {
+        const float t = dot(hp0 - p, hp0) / den;
+        const V q = normalized(p + e * t);
+        uv2 = V((float)((atan2f(q.y, q.x) / (2 * M_PI)) + .5), (float)(asinf(q.z) / M_PI + .5), 0.0f);   // objects.cpp:40-41
+        const float du = uv2.x - uvw.x;
+        if (du > 0.5f) uv2.x -= 1.0f;
+        if (du < -0.5f) uv2.x += 1.0f;
+      }
+    } else if (node.prim_kind == RT_PRIM_MESH) {
+      const rt_mesh& m = S.d.meshes[node.mesh_id];
+      if (m.uvw && m.uvw_idx && hit.face >= 0) {
+        const uint32_t* fi = &m.pos_idx[3 * (size_t)hit.face];
+        const V v0 = from3(&m.positions[3 * (size_t)fi[0]]), v1 = from3(&m.positions[3 * (size_t)fi[1]]), v2 = from3(&m.positions[3 * (size_t)fi[2]]);
+        const V e1 = v1 - v0, e2 = v2 - v0;
+        const V h = cross(e, e2);
+        const float det = dot(e1, h);
+        if (!(fabsf(det) < 1e-20f)) {
+          const float inv_det = 1.0f / det;
+          const V s = p - v0;
+          const float u = inv_det * dot(s, h);
+          const V q = cross(s, e1);
+          const float v = inv_det * dot(e, q);
+          const float w = 1.0f - u - v;
+          const uint32_t* ft = &m.uvw_idx[3 * (size_t)hit.face];
+          uv2 = (from3(&m.uvw[3 * (size_t)ft[0]]) * w) + (from3(&m.uvw[3 * (size_t)ft[1]]) * u) + (from3(&m.uvw[3 * (size_t)ft[2]]) * v);
+        }
+      }
+    }
+    hit.duvw[a] = uv2 - uvw;
+  }
+  hit.filtered = true;
+}
+
 Color send_ray(const orc_scene& S, const rt_render_params& P, int i, const Ray& ray, int x, int y, int W, int H,
                const Sampler& smp, Counters* cnt, Hit* primary_out) {
   Hit hit;
   if (cnt) { cnt->rays_primary++; cnt->paths++; }
   bool ok = trace_scene(S, ray, hit, RT_HIT_FRONT, cnt);
+  if (ok && hit.light < 0 && (P.extensions & RT_EXT_TEX_FILTER)) primary_differentials(S, P, ray, hit);
   if (primary_out) {
     *primary_out = hit;
     primary_out->aov_depth = ok ? hit.z * length(ray.dir) : BIGFLOAT;
@@ -1687,7 +1798,9 @@ Color send_ray(const orc_scene& S, const rt_render_params& P, int i, const Ray& 
     if (ok && hit.light < 0) {
       primary_out->aov_normal = normalized(hit.N);
       const rt_material& M = node_material(S, hit.node);
-      if (M.kind == RT_MTL_BLINN) primary_out->aov_albedo = eval_tex_color(S, M.diffuse, hit.uvw, nullptr);
+      const bool ext = (P.extensions & RT_EXT_MATERIALS) != 0;
+      if (M.kind == RT_MTL_BLINN || (ext && (M.kind == RT_MTL_PHONG || M.kind == RT_MTL_MICROFACET)))
+        primary_out->aov_albedo = eval_shade_color(S, M.diffuse, hit, nullptr);
     } else if (!ok) {
       primary_out->aov_albedo = eval_tex_color(S, S.d.background, V((float)x / (float)W, (float)y / (float)H, 0.0f), nullptr);
     }

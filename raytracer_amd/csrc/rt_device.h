@@ -98,7 +98,7 @@ struct DShadeInst {     // what k_shade needs of a hit instance in ONE record: t
   int32_t depth, xf_off;
   uint32_t shade_base, has_uvw;
   uint32_t uses_uvw;    // the material reads a texture map somewhere: only then are texture coordinates worth computing
-  uint32_t pad_;
+  uint32_t face_pos_base;  // meshes with texture coordinates: index of the mesh's first face in DScene::face_pos, else RT_NONE
   DMaterial mtl;
   uint32_t pad2_;
 };
@@ -117,6 +117,9 @@ struct DScene {
   const float4* tris;
   const float4* shade;  // per face, 5 float4: the three vertex normals and texture coordinates, indices resolved at commit
                         // (n0 | t0.x) (n1 | t0.y) (n2 | t0.z) (t1 | t2.x) (t2.y t2.z - -)
+  const float4* face_pos;  // per face of the meshes that have texture coordinates, 3 float4: v0, e1, e2 as DScene::tris holds
+                           // them per slot — the triangle a neighbouring pixel's ray is intersected with for the texture
+                           // coordinate derivatives (RT_EXT_TEX_FILTER, hit_differentials)
   const DMaterial* materials;
   const DTexmap* texmaps;
   const DImage* images;
@@ -144,6 +147,7 @@ struct DScene {
 #define RT_HPHI 512
 #define RT_HTHETA 1512
 #define RT_HGLOSS 2512
+#define RT_FILTER_TAPS 32   // Texture::Eval(uvw, duvw): sampleCount (scene.h:293); offsets behind the gloss tables: x[32], y[32]
 
 struct DCounters {  // mirrors rt_counters
   unsigned long long rays_primary, rays_secondary, rays_shadow, rays_photon;
@@ -1606,6 +1610,100 @@ RT_DEV V3 eval_environment(const DScene& S, DTexColor tc, V3 dir, Cnt<CNT>& cnt)
   float x = dir.x / (fabsf(dir.x) + fabsf(dir.y));
   float y = dir.y / (fabsf(dir.x) + fabsf(dir.y));
   return eval_tex_color<CNT>(S, tc, v3(0.5f + 0.5f * z * (x - y), 0.5f + 0.5f * z * (x + y), 0.0f), cnt);
+}
+
+// ---- RT_EXT_TEX_FILTER: Texture::Eval(uvw, duvw) (scene.h:289-303) — the texture averaged over RT_FILTER_TAPS lookups placed by
+// the Halton points (bases 2 and 3, wrapped to (-0.5, 0.5]) in the parallelogram the two derivatives span; TextureMap::Eval
+// (scene.h:338-343) takes the derivatives through the map's transform as directions.  A checker's colours are evaluated
+// unfiltered inside every tap (texture.cpp:136-140 calls color[..].Eval(uvw)).  With zero derivatives this IS the plain lookup
+// (scene.h:292), which is all the reference ever reaches: it never fills HitInfo::duvw.
+template <bool CNT>
+RT_DEV V3 texmap_tap(const DScene& S, const DTexmap& tm, V3 u, Cnt<CNT>& cnt) {
+  if (tm.kind == 2) return image_eval(S, S.images[tm.image], u);
+  const V3 t = tile_clamp(u);
+  const int k = (t.x <= 0.5f) ^ (t.y <= 0.5f);
+  return eval_tex_color<CNT>(S, tm.color[k], u, cnt);
+}
+template <bool CNT>
+RT_DEV V3 eval_tex_color_filtered(const DScene& S, DTexColor tc, V3 uvw, V3 d0, V3 d1, Cnt<CNT>& cnt) {
+  const V3 value = v3(tc.v[0], tc.v[1], tc.v[2]);
+  if (tc.map < 0) return value;
+  const DTexmap& tm = S.texmaps[tc.map];
+  const V3 u = xf_point(tm.itm, uvw), e0 = xf_dir(tm.itm, d0), e1 = xf_dir(tm.itm, d1);
+  cnt.tex();
+  V3 c = texmap_tap<CNT>(S, tm, u, cnt);
+  if (dot(e0, e0) + dot(e1, e1) == 0.0f) return value * c;
+  const float* tab = S.halton + RT_HGLOSS + 2 * S.n_gloss;
+  for (int i = 1; i < RT_FILTER_TAPS; i++) {
+    const float x = tab[i], y = tab[RT_FILTER_TAPS + i];
+    c = c + texmap_tap<CNT>(S, tm, u + x * e0 + y * e1, cnt);
+  }
+  return value * (c / (float)RT_FILTER_TAPS);
+}
+template <bool CNT>
+RT_DEV float eval_tex_float_filtered(const DScene& S, DTexFloat tf, V3 uvw, V3 d0, V3 d1, Cnt<CNT>& cnt) {
+  if (tf.map < 0) return tf.v;
+  DTexColor tc;
+  tc.v[0] = tc.v[1] = tc.v[2] = 1.0f;
+  tc.map = tf.map;
+  return tf.v * eval_tex_color_filtered<CNT>(S, tc, uvw, d0, d1, cnt).x;
+}
+
+// HitInfo::duvw (scene.h:82) as this build fills it for camera rays: the texture coordinates where the rays through the
+// neighbouring pixel to the right (dx) and below (dy), from the same origin, meet the surface's local approximation, minus
+// the hit's own — in the instance's space: the plane itself; the sphere's tangent plane at the hit, projected back onto the
+// sphere; the hit triangle's plane with its barycentric interpolation.  A ray parallel to that approximation gives 0.
+RT_DEV V3 sphere_uvw(V3 hp) {   // objects.cpp:40-41
+  return v3((float)(((double)atan2f(hp.y, hp.x) / (2 * RT_PI_D)) + .5), (float)((double)asinf(hp.z) / RT_PI_D + .5), 0.0f);
+}
+RT_DEV void hit_differentials(const DScene& S, const DShadeInst& I, V3 o, V3 dir, V3 dx, V3 dy, const Best& B, V3 uvw, V3& du0, V3& du1) {
+  const float* chain = S.xf + I.xf_off;
+  V3 p = o, d = dir, ex = dx, ey = dy;
+  for (int k = 0; k < I.depth; k++) {
+    const float* m = chain + 24 * k;
+    V3 np = xf_point(m, p), nd = xf_dir(m, d), nx = xf_dir(m, ex), ny = xf_dir(m, ey);
+    p = np; d = nd; ex = nx; ey = ny;
+  }
+  du0 = du1 = v3(0, 0, 0);
+  for (int a = 0; a < 2; a++) {
+    const V3 e = a ? ey : ex;
+    V3 uv2 = uvw;
+    if (I.prim == 2) {
+      if (!(fabsf(e.z) < 1e-8f)) {
+        const float t = -(p.z / e.z);
+        const V3 hp = p + e * t;
+        uv2 = v3((hp.x + 1.0f) * 0.5f, (hp.y + 1.0f) * 0.5f, 0.0f);
+      }
+    } else if (I.prim == 1) {
+      const V3 hp0 = p + (d * B.t);
+      const float den = dot(e, hp0);
+      if (!(fabsf(den) < 1e-8f)) {
+        const float t = dot(hp0 - p, hp0) / den;
+        uv2 = sphere_uvw(normalized(p + e * t));
+        const float du = uv2.x - uvw.x;   // the seam of atan2: the nearer way round
+        if (du > 0.5f) uv2.x -= 1.0f;
+        if (du < -0.5f) uv2.x += 1.0f;
+      }
+    } else if (I.has_uvw && I.face_pos_base != RT_NONE) {
+      const float4* fp = S.face_pos + 3 * ((size_t)I.face_pos_base + B.mh.face);
+      const float4 a0 = fp[0], a1 = fp[1], a2 = fp[2];
+      const V3 v0 = v3(a0.x, a0.y, a0.z), e1 = v3(a1.x, a1.y, a1.z), e2 = v3(a2.x, a2.y, a2.z);
+      const V3 h = cross(e, e2);
+      const float det = dot(e1, h);
+      if (!(fabsf(det) < 1e-20f)) {
+        const float inv_det = 1.0f / det;
+        const V3 s = p - v0;
+        const float u = inv_det * dot(s, h);
+        const V3 q = cross(s, e1);
+        const float v = inv_det * dot(e, q);
+        const float w = 1.0f - u - v;
+        const float4* fr = S.shade + 5 * ((size_t)I.shade_base + B.mh.face);
+        const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3], f4 = fr[4];
+        uv2 = (v3(f0.w, f1.w, f2.w) * w) + (v3(f3.x, f3.y, f3.z) * u) + (v3(f3.w, f4.x, f4.y) * v);
+      }
+    }
+    if (a) du1 = uv2 - uvw; else du0 = uv2 - uvw;
+  }
 }
 
 // Color24(Color) channel and Linear2sRGB as this build defines them (see oracle.cpp)

@@ -703,6 +703,8 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
   V3 w = v3(0, 0, 0), mabs = v3(0, 0, 0), cKd = v3(0, 0, 0), cKs = v3(0, 0, 0), kd = v3(0, 0, 0);
   float alpha = 0.0f, zs = 0.0f;
   int smode = 0;   // 0 MtlBlinn, 1 Phong lobe, 2 microfacet (cKs = F0, alpha = squared roughness): XM variants only
+  V3 du0 = v3(0, 0, 0), du1 = v3(0, 0, 0);   // HitInfo::duvw of a camera ray's hit (RT_EXT_TEX_FILTER): XM variants only
+  bool filt = false;
   float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
   ChildRay c_refr, c_refl, c_mc;
   bool p_refr = false, p_refl = false, p_mc = false, p_gather = false, refl_below = false;
@@ -719,6 +721,13 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
     } else {        // hit attributes of the closest hit the trace kernels found (+ the renderable lights)
       Hit h;
       finalize_hit_from(S, S.sinst, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), B, h);
+      if (XM && (P.extensions & RT_EXT_TEX_FILTER) && bounce == 0 && h.inst >= 0 && h.light < 0 && S.sinst[h.inst].uses_uvw) {
+        // camera rays carry differentials (HitInfo::duvw, scene.h:82): the rays through the pixels to the right and below
+        const V3 rd = v3(q1.x, q1.y, q1.z);
+        const V3 dxr = rd + v3(P.X[0], P.X[1], P.X[2]) * (P.ww / P.camW), dyr = rd - v3(P.Y[0], P.Y[1], P.Y[2]) * (P.wh / P.camH);
+        hit_differentials(S, S.sinst[h.inst], v3(q0.x, q0.y, q0.z), rd, dxr, dyr, B, h.uvw, du0, du1);
+        filt = true;
+      }
       h0 = make_float4(h.p.x, h.p.y, h.p.z, h.z);
       h1 = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((uint32_t)h.inst));
       h2 = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, __uint_as_float((h.front ? 1u : 0u) | ((uint32_t)(h.light + 1) << 8)));
@@ -783,12 +792,22 @@ RT_DEV void shade_point(const DScene& S, const PassP& P, const FrameBufs& F, con
         // materials.cpp:231-236
         // (one copy of the texture code in a loop that is not unrolled, results routed by selects, was measured: the
         // kernel shrinks by a third and runs 5 % SLOWER on C2 — the six inlined copies stay)
-        V3 reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
-        V3 refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
+        V3 reflection, refraction, ks, emission;
+        if (XM && filt) {   // ShadeInfo::Eval -> TexturedValue::Eval(uvw, duvw) (renderer.h:135-136) with the derivatives filled
+          reflection = eval_tex_color_filtered<CNT>(S, M.reflection, sp.uvw, du0, du1, cnt);
+          refraction = eval_tex_color_filtered<CNT>(S, M.refraction, sp.uvw, du0, du1, cnt);
+          kd = eval_tex_color_filtered<CNT>(S, M.diffuse, sp.uvw, du0, du1, cnt);
+          ks = eval_tex_color_filtered<CNT>(S, M.specular, sp.uvw, du0, du1, cnt);
+          alpha = eval_tex_float_filtered<CNT>(S, M.glossiness, sp.uvw, du0, du1, cnt);
+          emission = eval_tex_color_filtered<CNT>(S, M.emission, sp.uvw, du0, du1, cnt);
+        } else {
+        reflection = eval_tex_color<CNT>(S, M.reflection, sp.uvw, cnt);
+        refraction = eval_tex_color<CNT>(S, M.refraction, sp.uvw, cnt);
         kd = eval_tex_color<CNT>(S, M.diffuse, sp.uvw, cnt);
-        V3 ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
+        ks = eval_tex_color<CNT>(S, M.specular, sp.uvw, cnt);
         alpha = eval_tex_float<CNT>(S, M.glossiness, sp.uvw, cnt);
-        V3 emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
+        emission = eval_tex_color<CNT>(S, M.emission, sp.uvw, cnt);
+        }
         aov_a = kd;
         float diffScalar = (float)(1 / RT_PI_D);
         float specScalar = (float)(((double)(alpha + 2)) / (8 * RT_PI_D));

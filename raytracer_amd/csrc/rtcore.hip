@@ -779,6 +779,8 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   int max_mesh_depth = 0;
   std::vector<float4> bvh, tris;
   std::vector<float4> shade;   // DScene::shade
+  std::vector<float4> face_pos(1);   // DScene::face_pos (meshes with texture coordinates only)
+  std::vector<uint32_t> face_pos_base(sc->n_meshes, RT_NONE);
   for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
     const rt_mesh& m = sc->meshes[mi];
     if (!m.positions || !m.normals || !m.pos_idx || !m.nrm_idx || (m.bvh && (m.n_bvh_nodes == 0 || (m.n_faces && !m.bvh_elements))))
@@ -836,6 +838,19 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       r[4] = make_float4(t2[1], t2[2], 0.0f, 0.0f);
     }
     D.has_uvw = has_uvw ? 1 : 0;
+    if (has_uvw && m.n_faces) {   // the triangle in face order, edges by the reference's expression (objects.cpp:203-204)
+      if (((face_pos.size() / 3) + (size_t)m.n_faces) >> 32) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^32 faces");
+      face_pos_base[mi] = (uint32_t)(face_pos.size() / 3);
+      face_pos.resize(face_pos.size() + 3 * (size_t)m.n_faces);
+      for (size_t f = 0; f < (size_t)m.n_faces; f++) {
+        const float *a = m.positions + 3 * (size_t)m.pos_idx[3 * f], *b = m.positions + 3 * (size_t)m.pos_idx[3 * f + 1],
+                    *c = m.positions + 3 * (size_t)m.pos_idx[3 * f + 2];
+        float4* r = &face_pos[3 * ((size_t)face_pos_base[mi] + f)];
+        r[0] = make_float4(a[0], a[1], a[2], 0.0f);
+        r[1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.0f);
+        r[2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
+      }
+    }
   }
   {
     int32_t mk = 0;
@@ -897,7 +912,16 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
 
   // ---- Halton tables (values computed with the reference's float loop, rng.h:103-112)
   const int n_gloss = 4096;
-  std::vector<float> hal(RT_HGLOSS + 2 * n_gloss);
+  std::vector<float> hal(RT_HGLOSS + 2 * n_gloss + 2 * RT_FILTER_TAPS);
+  for (int i = 0; i < RT_FILTER_TAPS; i++) {   // Texture::Eval(uvw, duvw)'s tap offsets, its own float loops (scene.h:294-299)
+    float x = 0, y = 0, fx = 0.5f, fy = 1.0f / 3.0f;
+    for (int ix = i; ix > 0; ix /= 2) { x += fx * (ix % 2); fx /= 2; }
+    for (int iy = i; iy > 0; iy /= 3) { y += fy * (iy % 3); fy /= 3; }
+    if (x > 0.5f) x -= 1;
+    if (y > 0.5f) y -= 1;
+    hal[RT_HGLOSS + 2 * n_gloss + i] = x;
+    hal[RT_HGLOSS + 2 * n_gloss + RT_FILTER_TAPS + i] = y;
+  }
   for (int i = 0; i < 128; i++) {
     hal[RT_H2 + i] = halton_ref(i, 2); hal[RT_H3 + i] = halton_ref(i, 3);
     hal[RT_H5 + i] = halton_ref(i, 5); hal[RT_H7 + i] = halton_ref(i, 7);
@@ -917,6 +941,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
       std::memset(&R, 0, sizeof R);
       R.prim = inst[i].prim; R.node = inst[i].node; R.depth = inst[i].depth; R.xf_off = inst[i].xf_off;
       R.shade_base = inst[i].prim == RT_PRIM_MESH ? inst[i].shade_base : 0u; R.has_uvw = inst[i].has_uvw;
+      R.face_pos_base = inst[i].prim == RT_PRIM_MESH ? face_pos_base[inst[i].mesh] : RT_NONE;
       R.mtl = mtls[inst[i].mtl];
       const DMaterial& M = R.mtl;
       R.uses_uvw = (M.diffuse.map >= 0 || M.specular.map >= 0 || M.emission.map >= 0 || M.reflection.map >= 0 || M.refraction.map >= 0 ||
@@ -943,6 +968,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   }
   if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, shade, &D.shade))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, face_pos, &D.face_pos))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, mtls, &D.materials))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, tms, &D.texmaps))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, imgs, &D.images))) return rc;

@@ -254,6 +254,80 @@ def check_extended_materials(r, w=160, h=90, spp=4, photons=True):
         assert len(r.GetCausticsMap()) < n_caus, "the stubs' GenerateSample returns false"
 
 
+TEXFILTER = """<xml><scene>
+  <object type="plane" name="floor" material="fine"> <scale value="60"/> </object>
+  <object type="sphere" name="globe" material="clouds"> <scale value="3"/> <rotate angle="25" x="1"/> <translate x="-5" y="2" z="3"/> </object>
+  <object type="obj" name="tests/golden/meshes/mm_mapks.obj"> <scale value="2.2"/> <rotate angle="-30" z="1"/> <translate x="5" y="1" z="0"/> </object>
+  <object type="plane" name="wall" material="bricks"> <scale value="12"/> <rotate angle="90" x="1"/> <translate y="30" z="12"/> </object>
+  <material type="blinn" name="fine">
+    <diffuse texture="checkerboard"> <color1 r="0.95" g="0.95" b="0.9"/> <color2 r="0.05" g="0.05" b="0.1"/> <scale value="0.01"/> </diffuse>
+    <specular value="0"/> </material>
+  <material type="blinn" name="clouds"> <diffuse value="0.9" texture="scenes/tex_clouds.png"> <scale x="0.25" y="0.5" z="1"/> </diffuse>
+    <specular value="0.3"/> <glossiness texture="scenes/tex_bricks.png" value="60"/> </material>
+  <material type="blinn" name="bricks"> <diffuse texture="scenes/tex_bricks.png"> <scale value="0.2"/> </diffuse> <specular value="0"/> </material>
+  <light type="direct"> <intensity value="0.9"/> <direction x="0.3" y="0.8" z="-1"/> </light>
+  <light type="point"> <intensity value="120"/> <position x="0" y="-6" z="12"/> <attenuation value="1"/> </light>
+  <background r="0.2" g="0.3" b="0.5"/>
+</scene>
+<camera> <position x="0" y="-20" z="4"/> <target x="0" y="10" z="2"/> <up x="0" y="0" z="1"/> <fov value="45"/>
+  <width value="160"/> <height value="90"/> </camera></xml>"""
+
+
+def check_texture_filter(r, w=160, h=90, ref_spp=64):
+    """SURVEY 8f n4, RT_EXT_TEX_FILTER: camera rays carry differentials into HitInfo::duvw (this build's definition) and the
+    material parameters go through the reference's filtered lookup Texture::Eval(uvw, duvw) (scene.h:289-303), restated in the
+    oracle.  Plane, sphere and mesh hits, checker and image textures, a textured glossiness.  Without texture maps, or with
+    the extension off, nothing changes; with it the device agrees with the oracle and the 1-spp frame is nearer to a
+    supersampled one than the unfiltered 1-spp frame is."""
+    import oracle_ffi
+    from conftest import ROOT
+    from raytracer_amd import Scene
+    from raytracer_amd._ffi import RT_EXT_TEX_FILTER
+    scene = Scene.from_string(TEXFILTER, asset_dir=ROOT)
+    assert scene.warnings == 0
+    r.LoadScene(scene)
+    orc = oracle_ffi.OracleScene(scene)
+    p0 = params(w, h, spp=1, jitter=0, bounces=0)
+    p1 = params(w, h, spp=1, jitter=0, bounces=0)
+    p1.extensions = RT_EXT_TEX_FILTER
+    g0, g1, c0, c1 = r.Render(p0), r.Render(p1), orc.render(p0), orc.render(p1)
+    assert np.array_equal(g1.hit_node, c1.hit_node) and np.array_equal(g1.hit_face, c1.hit_face)
+    assert len(np.unique(c1.hit_node[c1.hit_node >= 0])) >= 4 and (c1.hit_face >= 0).sum() > 100
+    assert rel_colour_diff(g0.radiance, c0.radiance) <= 1e-4
+    d = np.abs(g1.radiance[..., :3] - c1.radiance[..., :3]) / np.maximum(np.abs(c1.radiance[..., :3]), 1e-3)
+    within = (d.max(axis=-1) <= 1e-4).mean()
+    mean = float(np.abs(g1.radiance[..., :3] - c1.radiance[..., :3]).mean())
+    print(f"texture filter: {within:.5f} of the pixels within 1e-4, PSNR {psnr8(g1.img, c1.img):.1f} dB, mean |diff| {mean:.3g}")
+    # (a tap that lands within an ulp of a checker edge or a texel border may fall on the other side: 1/32 of one pixel's colour)
+    assert within >= 0.999 and psnr8(g1.img, c1.img) >= 60.0 and mean <= 1e-5, (within, psnr8(g1.img, c1.img), mean)
+    assert np.allclose(g1.albedo, c1.albedo, atol=2e-3)
+    changed = np.abs(c1.radiance[..., :3] - c0.radiance[..., :3]).max(axis=-1) > 1e-3
+    assert changed.mean() > 0.1, "the filter changes nothing"
+    # against a supersampled frame (jittered, unfiltered, oracle): the filtered 1-spp frame is the nearer one on every object kind
+    pr = params(w, h, spp=ref_spp, jitter=1, bounces=0)
+    ref = orc.render(pr, 8)
+    for name in ("floor", "globe", "wall"):
+        node = [i for i in range(scene.desc.n_nodes) if scene.node_name(i) == name][0]
+        sel = (c1.hit_node == node)
+        e0 = float(((c0.radiance[sel][:, :3] - ref.radiance[sel][:, :3]) ** 2).mean())
+        e1 = float(((c1.radiance[sel][:, :3] - ref.radiance[sel][:, :3]) ** 2).mean())
+        print(f"  {name}: mse unfiltered {e0:.3g}, filtered {e1:.3g}")
+        assert sel.sum() > 100 and e1 < e0, (name, e0, e1)
+    # secondary hits carry no derivatives and a scene without texture maps none at all: bit-equal frames
+    plain = Scene.load(__import__("conftest").scene_path("spheres_room.xml"))
+    r.LoadScene(plain)
+    q0 = params(96, 64, spp=2, jitter=1, bounces=2)
+    q1 = params(96, 64, spp=2, jitter=1, bounces=2)
+    q1.extensions = RT_EXT_TEX_FILTER
+    a, b = r.Render(q0), r.Render(q1)
+    assert np.array_equal(a.hit_node, b.hit_node) and np.allclose(a.radiance, b.radiance, rtol=1e-6, atol=1e-7)
+    # stochastic frame with bounces on the textured scene: camera hits filtered, secondary hits not
+    r.LoadScene(scene)
+    s1 = params(w, h, spp=2, jitter=1, bounces=2)
+    s1.extensions = RT_EXT_TEX_FILTER
+    print("texture filter, stochastic", assert_stochastic_close(r.Render(s1), orc.render(s1), "texture filter", frac=0.998, psnr=60.0, mean=1e-5))
+
+
 def check_edge_cases(r):
     """Empty scene, scene without lights, a default-material node, ragged image sizes (partial 32x32 tiles,
     partial 64-path wave tiles), 1x1 image, empty ray batches."""

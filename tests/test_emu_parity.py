@@ -277,6 +277,10 @@ def test_extended_materials(emu):
     common_checks.check_extended_materials(emu, w=96, h=54, spp=2)
 
 
+def test_texture_filter(emu):
+    common_checks.check_texture_filter(emu, w=96, h=54, ref_spp=32)
+
+
 def test_boundary_extras(emu):
     common_checks.check_boundary_extras(emu)
 

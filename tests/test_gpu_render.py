@@ -5,7 +5,7 @@ import pytest
 import oracle_ffi
 import os
 
-from common import assert_stochastic_close, check_boundary_extras, check_extended_materials, check_edge_cases, check_philox_on_device, check_random_scene_graphs, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
+from common import assert_stochastic_close, check_boundary_extras, check_extended_materials, check_texture_filter, check_edge_cases, check_philox_on_device, check_random_scene_graphs, check_geometry_buffers, check_instance_bvh, params, psnr8, rel_colour_diff
 from conftest import ROOT, scene_path
 from raytracer_amd import Scene
 
@@ -116,6 +116,10 @@ def test_instance_bvh_matches_scene_graph_walk(gpu_renderer, monkeypatch):
 
 def test_extended_materials(gpu_renderer):
     check_extended_materials(gpu_renderer)
+
+
+def test_texture_filter(gpu_renderer):
+    check_texture_filter(gpu_renderer)
 
 
 def test_boundary_extras(gpu_renderer):
