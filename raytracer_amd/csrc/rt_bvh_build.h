@@ -118,7 +118,7 @@ RT_KERNEL(k_lbvh_split, LbvhArgs A, int level) {
       if ((unsigned long long)(m - lo) <= cap && (unsigned long long)(hi - m) <= cap) mid = m;
     }
     const uint32_t lref = lbvh_child(A, lo, mid), rref = lbvh_child(A, mid, hi);
-    A.nodes[4 * (size_t)me + 3] = make_float4(__uint_as_float(lref), __uint_as_float(rref), 0.0f, 0.0f);
+    A.nodes[4 * (size_t)me + 3] = make_float4(__uint_as_float(lref), __uint_as_float(rref), __uint_as_float(mid), 0.0f);   // .z: first slot of the right child
   }
 }
 

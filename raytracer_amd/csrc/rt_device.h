@@ -1420,6 +1420,9 @@ struct MeshWalk {
   uint32_t next;       // the ray's next candidate (RT_NONE: this is the last one)
   int inst;            // instance being walked
   bool fast;           // reciprocal direction finite: min3/max3 slab test (bit-identical decisions, see box_test_fast)
+  uint32_t minst;      // ... and its position in DScene::minst_rec
+  uint32_t hint;       // any-hit walks (k_shadow_mesh): the triangle slot to head for first while `onpath`
+  bool onpath;         // the walk stands on the path from the root to the hinted slot
 };
 #define RT_NOREF 0xFFFFFFFFu
 RT_DEV bool ref_is_node(uint32_t r) { return !(r & RT_LEAF); }                  // (RT_NOREF has the leaf bit)
@@ -1438,6 +1441,7 @@ RT_DEV void mesh_walk_enter(const DScene& S, const float4* cand, uint32_t ci, Me
   W.fast = inv_is_finite(W.inv);
   W.next = __float_as_uint(c1.w);
   W.cur = R.root_ref; W.pend = 0; W.sp = 0; W.inst = R.inst;
+  W.minst = __float_as_uint(c0.w);
   W.node_base = R.node_base; W.tri_base = R.tri_base;
 }
 
@@ -1461,7 +1465,10 @@ RT_DEV uint32_t walk_pop(MeshWalk& W, uint32_t* stk, uint32_t stride) {
 // reference (RT_NOREF when nothing is left).  ORDERED: the nearer child first (closest hit); otherwise the fixed
 // child order of the any-hit walk (see mesh_any_t).  Written without nested branches: one predicated LDS write (both
 // children hit), one predicated LDS read (neither hit), selects for the rest.
-template <bool CNT, bool ORDERED>
+// HINT (any-hit walks only): while the walk is on the path to W.hint, the child whose slot range holds that slot goes first —
+// n3.z is the first slot of the right child's range (the children cover consecutive ranges) — and the walk stays on the
+// path iff it entered that child.
+template <bool CNT, bool ORDERED, bool HINT = false>
 RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 n3, float bound_t, uint32_t* stk, uint32_t stride,
                            Cnt<CNT>& cnt) {
   float tl, tr;
@@ -1475,6 +1482,11 @@ RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 
   }
   uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
   bool left_first = ORDERED ? (tl <= tr) : true;
+  if (HINT) {
+    const bool hint_left = W.hint < __float_as_uint(n3.z);
+    if (W.onpath) left_first = hint_left;
+    W.onpath = W.onpath && (hint_left ? hl : hr);
+  }
   bool both = hl && hr, any = hl || hr;
   uint32_t nearc = (hl && (!hr || left_first)) ? cl : cr;
   uint32_t farc = left_first ? cr : cl;
@@ -1515,7 +1527,7 @@ RT_DEV void mesh_walk_leaf_closest(const DScene& S, const MeshWalk& W, uint32_t 
 }
 // Leaf step of the any-hit walk: true when a triangle of leaf `ref` has t in (0.002, t_max) (objects.cpp:341-371).
 template <bool CNT>
-RT_DEV bool mesh_walk_leaf_any(const DScene& S, const MeshWalk& W, uint32_t ref, float t_max, Cnt<CNT>& cnt) {
+RT_DEV bool mesh_walk_leaf_any(const DScene& S, const MeshWalk& W, uint32_t ref, float t_max, Cnt<CNT>& cnt, uint32_t& at_slot) {
   const float4* tris = S.tris + W.tri_base;
   uint32_t count = ref & 7u, first = (ref & 0x7fffffffu) >> 3;
   bool occluded = false;
@@ -1527,7 +1539,7 @@ RT_DEV bool mesh_walk_leaf_any(const DScene& S, const MeshWalk& W, uint32_t ref,
     float t, u, v;
     cnt.tri();
     if (tri_test(W.p, W.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
-      if (t > 0.002f && t < t_max) { occluded = true; break; }
+      if (t > 0.002f && t < t_max) { occluded = true; at_slot = first + s; break; }
     a = na; b = nb; c = nc;
   }
   return occluded;

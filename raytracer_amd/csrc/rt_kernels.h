@@ -40,6 +40,8 @@ struct GroupQ {  // one record per (shade point, light) whose unshadowed contrib
   float4* g2;    // disc offsets rx, ry (lights.cpp:25-26), lit-sample counter, unused
   float4* g3;    // soft groups: disc tangent (lights.cpp:32), light size     -- the same for every sample of the group,
   float4* g4;    // soft groups: disc bitangent, instances that may occlude      computed once by k_shade
+  uint2* hint;   // soft groups: where the group's last occluded ray found its occluder (mesh instance, triangle slot) — an
+                 // ordering hint for the second phase's walks (k_shadow_mesh), never read for a result; may hold anything
   uint32_t* counts;
   uint32_t segcap;
   uint32_t nseg;
@@ -454,6 +456,7 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
   W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
+  W.hint = 0; W.onpath = false; W.minst = RT_NONE;
   MeshHit L;
   L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
   bool lfound = false;
@@ -1055,8 +1058,11 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_shade, DScene S, PassP P, FrameBufs F, RayQ Q, Ray
 // form, for three quarters of C2's rays and all of C3's).  A ray with mesh candidates is appended to the compact queue QM
 // (entry + work item at the same index, one atomic per wave), walked by k_trace_mesh and shaded by k_shade, which then
 // sees nothing but mesh hits.  Children of both go to QN, in the parent's segment.
+#ifndef RT_FUSED_WAVES
+#define RT_FUSED_WAVES RT_SHADE_WAVES   // the fused kernels at 3 / 4 / 5 waves per SIMD: C3 k_trace_shade 20.9 / 19.3 / 21.4 ms, C2 k_raygen_shade 3.80 / 3.25 / 3.86 ms
+#endif
 template <bool CNT, bool TLAS, bool MC, bool PH, bool XM>
-RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint32_t* l0_counts, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS,
+RT_KERNEL_W(RT_FUSED_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint32_t* l0_counts, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS,
             GatherQ GQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
@@ -1113,7 +1119,7 @@ RT_KERNEL_W(RT_SHADE_WAVES, k_raygen_shade, DScene S, PassP P, FrameBufs F, uint
 
 // Secondary rays (level >= 1): the children k_shade / the fused kernels appended to Q.
 template <bool CNT, bool TLAS, bool MC, bool PH, bool XM>
-RT_KERNEL_W(RT_SHADE_WAVES, k_trace_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
+RT_KERNEL_W(RT_FUSED_WAVES, k_trace_shade, DScene S, PassP P, FrameBufs F, RayQ Q, RayQ QM, MeshQ MQ, RayQ QN, GroupQ GH, GroupQ GS, GatherQ GQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
   uint32_t traced = 0, n_shades = 0;
@@ -1293,7 +1299,19 @@ RT_KERNEL_W(RT_SHADOW_P1_WAVES, k_shadow_soft, DScene S, PassP P, FrameBufs F, G
 #ifndef RT_SHADOW_MESH_WAVES
 #define RT_SHADOW_MESH_WAVES 6   // 4 -> 4.19 ms, 5 -> 3.81 ms, 6 -> 3.59 ms, 8 -> 4.56 ms per C2 step
 #endif
-template <bool CNT, bool SOFT>
+// Occluder hints.  An any-hit walk may visit the children in any order, and most shadow rays that reach a mesh ARE occluded
+// (C5: 85 %, and a ray needed 59 node steps to find its occluder walking nearer-child-first: the ground under its origin
+// comes first).  Rays that follow each other through a lane — samples of one soft-shadow group, shadow rays of neighbouring
+// shade points — are mostly blocked by the same piece of geometry, so a walk is given the triangle slot that blocked the
+// previous ray (of its group: GroupQ::hint, else of its lane) and, while it stands on the path to that slot, descends
+// towards it first: a node's children cover consecutive slot ranges and the node record names where the right one begins.
+// The walk tests exactly the boxes on that path, the hinted leaf, and then carries on from its stack with the leaf's
+// neighbours; nothing is skipped and nothing extra is tested that a full walk would not test, so the answer is the one
+// TraceBVHNodeShadow gives (objects.cpp:341-371) whatever the hint holds.  Measured (MI355X): C5 (12.6 M triangles, trees 24 deep)
+// k_shadow_mesh 758 -> 520 ms per step; C2 (81 k triangles, hard shadows) 2.49 -> 2.59 ms and finalProject 13.4 -> 13.7 ms —
+// there an occluder is found in ~18 steps anyway and the six extra instructions per node step are all that shows.  HINT is
+// therefore a kernel variant, used for soft-shadow walks of scenes whose mesh trees are deep (rt_scene_commit, "shadow_hints").
+template <bool CNT, bool SOFT, bool HINT>
 RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F, GroupQ G, MeshQ MQ) {
   RT_STACK_DECL
   Cnt<CNT> cnt;
@@ -1304,11 +1322,13 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   uint32_t group = 0;
   float tmax = 0.0f;
   uint32_t guard = 0;
+  uint32_t hint_minst = RT_NONE, hint_slot = 0;   // the lane's current hint: (position in DScene::minst_rec, triangle slot)
   MeshWalk W;
   W.p = W.d = W.inv = v3(0, 0, 0);
   W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
+  W.hint = 0; W.onpath = false; W.minst = RT_NONE;
   for (;;) {  // one wave-wide step per iteration, as in k_trace_mesh
-    if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+    if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); W.onpath = false; }
     if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) state = RT_ST_NEXT;
     const bool walking = state == RT_ST_WALK;
     const bool at_node = walking && ref_is_node(W.cur);
@@ -1339,11 +1359,17 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
           group = it.x;
           enter = it.z;
           tmax = __uint_as_float(it.w);   // (the ray itself is in the candidates, already in each instance's space)
+          if (SOFT && HINT) {  // the group's own hint, when it has one for a mesh (else the lane keeps its last)
+            const uint2 gh = G.hint[group];
+            if (gh.x < (uint32_t)S.n_minst) { hint_minst = gh.x; hint_slot = gh.y; }
+          }
         }
         if (exhausted) { seg = (seg + 1) % nseg; segs_done++; }
       }
       if (enter != RT_NONE) {
         mesh_walk_enter<CNT>(S, MQ.cand, enter, W, cnt);
+        W.hint = hint_slot;
+        W.onpath = HINT && W.minst == hint_minst;
         state = RT_ST_WALK;
       }
       continue;
@@ -1351,17 +1377,24 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
     if (n_node != 0 && (n_pend < RT_LEAF_MIN || n_node >= RT_WAVE / 2) && (n_node >= RT_NODE_MIN || n_pend < RT_NODE_MIN)) {
 #pragma unroll
       for (int k = 0; k < RT_NODE_BATCH; k++) {
-        if (k > 0 && walking && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); }
+        if (k > 0 && walking && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); W.onpath = false; }
         if (walking && ref_is_node(W.cur)) {
           float4 n0, n1, n2, n3;
           fetch_node(S, W, true, n0, n1, n2, n3);
-          mesh_walk_node<CNT, RT_SHADOW_ORDERED != 0>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+          mesh_walk_node<CNT, RT_SHADOW_ORDERED != 0, HINT>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
         }
       }
     } else if (walking && W.pend != 0) {
-      bool occluded = mesh_walk_leaf_any<CNT>(S, W, W.pend, tmax, cnt);
+      uint32_t at_slot = 0;
+      bool occluded = mesh_walk_leaf_any<CNT>(S, W, W.pend, tmax, cnt, at_slot);
       W.pend = 0;
-      if (occluded) state = RT_ST_IDLE;
+      if (occluded) {
+        state = RT_ST_IDLE;
+        if (HINT && (hint_minst != W.minst || hint_slot != at_slot)) {
+          hint_minst = W.minst; hint_slot = at_slot;
+          if (SOFT) { uint2 gh; gh.x = hint_minst; gh.y = hint_slot; G.hint[group] = gh; }
+        }
+      }
     }
   }
   if (CNT) cnt.flush(F.counters);

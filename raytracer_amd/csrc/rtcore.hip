@@ -74,6 +74,9 @@
 #ifndef RT_SOFT_CHUNK
 #define RT_SOFT_CHUNK 32   // soft-shadow samples per launch of the second sample phase when the scene has meshes (run_pass)
 #endif
+#ifndef RT_SHADOW_HINT_DEPTH
+#define RT_SHADOW_HINT_DEPTH 19   // mesh trees at least this deep (~1 M triangles) walk their soft-shadow rays with occluder hints
+#endif
 #ifndef RT_TRACE_BLOCKS_PER_CU
 #define RT_TRACE_BLOCKS_PER_CU 6   // traversal kernels: at most this many blocks per CU, fewer when the scene's stack needs the LDS
 #endif
@@ -122,6 +125,8 @@ struct Options {
   double soft_clear = 1;           // "soft_clear"   RT_SOFT_CLEAR    0: trace every soft-shadow group (tests compare both)
   double fuse = 1;                 // "fuse"         RT_FUSE          1: first trace phase + shading in one kernel (k_raygen_shade / k_trace_shade);
                                    //                                  0: the separate k_raygen_trace / k_trace_closest / k_shade launches
+  double shadow_hints = -1;        // "shadow_hints" RT_SHADOW_HINTS   soft-shadow mesh walks head for the previous ray's occluder first: 1 on, 0 off,
+                                   //                                  -1 by the depth of the scene's mesh trees (>= RT_SHADOW_HINT_DEPTH)
   double cone_max_inst = RT_CONE_MAX_INST;   // "cone_max_inst"  instances up to which the soft-shadow proofs walk the instance table; beyond it
                                              //                  (with an instance BVH) every group's cone walks the BVH (tests force both)
 };
@@ -139,6 +144,7 @@ struct rt_context {
   DevMem bufs[SC_COUNT];
   uint64_t n_allocs = 0;   // hipMalloc calls made on behalf of this context (rt_debug_alloc_count)
   int max_blocks = 2048, max_blocks_trace = 1024;
+  int max_mesh_depth = 0;   // deepest mesh BVH of the committed scene
   int n_cus = 256;
   size_t trace_lds = (size_t)RT_STACK * RT_BLOCK * 4;   // dynamic LDS of the traversal kernels: stack entries of the scene x block
   bool has_scene = false;
@@ -352,12 +358,13 @@ struct MeshConv {
     const rt_bvh_node& r = m.bvh[n.b];
     uint32_t lref, rref;
     if (!convert(n.a, depth + 1, lref)) return false;
+    const uint32_t right_first = n_slots;   // the children cover consecutive slot ranges: the right one's begins here (occluder hints)
     if (!convert(n.b, depth + 1, rref)) return false;
     // per axis: (left min, right min, left max, right max) — the two children's slab tests run as packed FP32 pairs
     nodes[at + 0] = make_float4(l.bmin[0], r.bmin[0], l.bmax[0], r.bmax[0]);
     nodes[at + 1] = make_float4(l.bmin[1], r.bmin[1], l.bmax[1], r.bmax[1]);
     nodes[at + 2] = make_float4(l.bmin[2], r.bmin[2], l.bmax[2], r.bmax[2]);
-    nodes[at + 3] = make_float4(host_u2f(lref), host_u2f(rref), 0.0f, 0.0f);
+    nodes[at + 3] = make_float4(host_u2f(lref), host_u2f(rref), host_u2f(right_first), 0.0f);
     ref = me;
     return true;
   }
@@ -620,6 +627,7 @@ int rt_context_create(int device_id, rt_context** out) {
   env("RT_TEST_FAN_SCALE", ctx->opt.fan_scale);
   if (std::getenv("RT_TIMING")) ctx->opt.timing = 1;
   if (const char* e = std::getenv("RT_SOFT_CLEAR")) ctx->opt.soft_clear = std::atof(e);
+  if (const char* e = std::getenv("RT_SHADOW_HINTS")) ctx->opt.shadow_hints = std::atof(e);
   env("RT_FUSE", ctx->opt.fuse);
   *out = ctx;
   return RT_OK;
@@ -637,6 +645,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "soft_clear") ctx->opt.soft_clear = value;
   else if (n == "cone_max_inst") ctx->opt.cone_max_inst = value;
   else if (n == "fuse") ctx->opt.fuse = value;
+  else if (n == "shadow_hints") ctx->opt.shadow_hints = value;
   else if (n == "shadow_tlas_min") ctx->opt.shadow_tlas_min = value;   // takes effect at the next rt_scene_commit
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
   return RT_OK;
@@ -1015,6 +1024,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   }
   {  // traversal stack: one entry per BVH level that can hold a deferred sibling (+ the instance BVH's when it is used,
      // whose one-phase walk nests the mesh walk above its own entries)
+    ctx->max_mesh_depth = max_mesh_depth;
     int entries = max_mesh_depth + 2 + (D.use_tlas ? tlas_depth + 2 : 0);
     entries = std::max(4, std::min(entries, (int)RT_STACK));
 #ifndef RT_EMU
@@ -1682,7 +1692,10 @@ int ensure_frame(rt_context* ctx, const FramePlan& fp) {
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g0 = (float4*)pp;
     if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g1 = (float4*)pp;
     g.g2 = g.g3 = g.g4 = nullptr;
+    g.hint = nullptr;
     if (with_g2) {
+      if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 8, &pp))) return r; g.hint = (uint2*)pp;
+      HIP_TRY(hipMemsetAsync(pp, 0xff, cap * 8, ctx->stream));   // (no hint; the array is never cleared again: any value is only a hint)
       if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g2 = (float4*)pp;
       if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g3 = (float4*)pp;
       if ((r = alloc_dev(ctx, ctx->frame_mem, cap * 16, &pp))) return r; g.g4 = (float4*)pp;
@@ -1796,6 +1809,9 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
   const bool fuse = ctx->opt.fuse != 0 && !ctx->ds.use_tlas;
   const bool mc = P.mc_bounces > 0, ph = P.photons != 0;
   const bool xm = P.extensions != 0;
+  // occluder hints for the soft-shadow mesh walks (k_shadow_mesh): they pay where finding an occluder nearer-child-first
+  // takes many more steps than a tree is deep — large meshes — and cost ~4 % where it does not
+  const bool hints = ctx->opt.shadow_hints > 0 || (ctx->opt.shadow_hints < 0 && ctx->max_mesh_depth >= RT_SHADOW_HINT_DEPTH);
 #define RT_SHADE(n_, Q_)                                                                                        \
   do {                                                                                                          \
     if (xm) {                                                                                                   \
@@ -1896,7 +1912,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GH));
       if (meshes) {
         Timer t2(ctx, RT_K_SHADOW_MESH);
-        LAUNCH_T((k_shadow_mesh<CNT, false>), std::min<uint64_t>(gh_ub, (uint64_t)MH.segcap * MH.nseg), ctx->ds, P, F, GH, MH);
+        LAUNCH_T((k_shadow_mesh<CNT, false, false>), std::min<uint64_t>(gh_ub, (uint64_t)MH.segcap * MH.nseg), ctx->ds, P, F, GH, MH);
         t2.stop((uint64_t)(lvl * CNT_KINDS + CNT_MH));
       }
     }
@@ -1926,7 +1942,8 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
       }
       if (meshes) {
         Timer t(ctx, RT_K_SHADOW_MESH);
-        LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
+        if (hints) LAUNCH_T((k_shadow_mesh<CNT, true, true>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
+        else LAUNCH_T((k_shadow_mesh<CNT, true, false>), std::min<uint64_t>(gs_ub * (uint64_t)P.shadow_min, ms_cap), ctx->ds, P, F, GS, MS1);
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS1));
       }
       LAUNCH(k_shadow_soft_decide, gs_ub, P, F, GS, list1, (const uint32_t*)n1, ctx->d_list2, n2);
@@ -1955,7 +1972,8 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
           }
           if (meshes) {
             Timer t(ctx, RT_K_SHADOW_MESH);
-            LAUNCH_T((k_shadow_mesh<CNT, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
+            if (hints) LAUNCH_T((k_shadow_mesh<CNT, true, true>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
+            else LAUNCH_T((k_shadow_mesh<CNT, true, false>), std::min<uint64_t>(gs_ub * (uint64_t)nr, ms_cap), ctx->ds, P, F, GS, MS2);
             t.stop((uint64_t)(lvl * CNT_KINDS + CNT_MS2));
           }
           j0 += nr;

@@ -578,6 +578,33 @@ def check_stress_scene(r, scene, w, h, n_rays, oracle_scene=None):
     return g, c
 
 
+def check_shadow_hints(r, scene, w, h, spp=1, tol=5e-5, device_bvh=False):
+    """Occluder hints of the soft-shadow mesh walks (k_shadow_mesh<.., HINT>): an any-hit walk may visit children in any order,
+    so the frame with hints forced on equals the frame with hints off — per pixel to the order of the float atomics — and
+    both equal the oracle's.  Run on the stress scene's shape (rays start on the mesh that shadows them)."""
+    import oracle_ffi
+    frames = []
+    for on in (0, 1):
+        r.set_option("shadow_hints", on)
+        try:
+            r.LoadScene(scene)
+            p = params(w, h, spp=spp, jitter=1, bounces=1)
+            r.counters(enable=True, reset=True)
+            frames.append(r.Render(p))
+            frames[-1].node_visits = r.counters()["node_visits"]
+            r.counters(enable=False)
+        finally:
+            r.set_option("shadow_hints", -1)
+    a, b = frames
+    assert np.array_equal(a.hit_node, b.hit_node)
+    assert np.abs(a.radiance[..., :3] - b.radiance[..., :3]).max() <= 1e-5, np.abs(a.radiance[..., :3] - b.radiance[..., :3]).max()
+    c = oracle_ffi.OracleScene(scene.with_bvh({0: r.GetMeshBVH(0)}) if device_bvh else scene).render(params(w, h, spp=spp, jitter=1, bounces=1))
+    assert np.abs(b.radiance[..., :3] - c.radiance[..., :3]).max() <= tol, np.abs(b.radiance[..., :3] - c.radiance[..., :3]).max()
+    shadowed = (c.radiance[..., :3].sum(axis=-1) < 0.5 * np.median(c.radiance[..., :3].sum(axis=-1))).mean()
+    print(f"shadow hints: node visits {a.node_visits} -> {b.node_visits} ({b.node_visits / a.node_visits:.3f}), dark pixels {shadowed:.2f}")
+    return a.node_visits, b.node_visits
+
+
 def mesh_arrays(m):
     """positions (nv, 3) and position index triples (nf, 3) of an rt_mesh"""
     pos = np.ctypeslib.as_array(m.positions, shape=(m.n_positions, 3)).copy()

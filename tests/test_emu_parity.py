@@ -88,6 +88,14 @@ def test_stress_scene_scaled(emu):
     assert np.abs(g.radiance[..., :3] - c.radiance[..., :3]).max() <= 5e-5
 
 
+def test_shadow_hints_change_the_walk_only(emu):
+    scene = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90)
+    off, on = common_checks.check_shadow_hints(emu, scene, 64, 36)
+    assert on < off   # fewer node visits to the same answers
+    bare = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90, host_bvh=False)
+    common_checks.check_shadow_hints(emu, bare, 48, 27, device_bvh=True)   # the device-built tree names its slot ranges too
+
+
 def test_soft_shadow_clear_view_shortcut(emu):
     """Cornell box with a sphere light (nested transforms, planes and spheres) and the textured C3 scene."""
     n1, n0 = common_checks.check_soft_shadow_clear_view(emu, Scene.load(scene_path("cornell_box.xml")), 64, 48, strict=1e-4)

@@ -59,6 +59,15 @@ def test_c5_stress_scene_scaled(gpu_renderer):
     print("c5 scaled:", cc.assert_stochastic_close(g, c, "stress scene"))
 
 
+def test_shadow_hints_change_the_walk_only(gpu_renderer):
+    """k_shadow_mesh with and without occluder hints on the scaled stress scene (host SAH tree and device-built tree)."""
+    scene = Scene.stress(seed=7, n_instances=96, subdiv=3, ground_res=230, width=480, height=270)
+    off, on = cc.check_shadow_hints(gpu_renderer, scene, 240, 135, spp=2)
+    assert on < off
+    bare = Scene.stress(seed=7, n_instances=96, subdiv=3, ground_res=230, width=480, height=270, host_bvh=False)
+    cc.check_shadow_hints(gpu_renderer, bare, 160, 90, device_bvh=True)
+
+
 def test_soft_shadow_clear_view_shortcut(gpu_renderer):
     """Soft-shadow groups with a proven clear view of the light are fully lit, and groups in the full shadow of a sphere dark,
     without tracing (cone_clear): same frame as with every group traced, oracle parity, and fewer rays — on the Cornell box,
