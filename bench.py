@@ -439,22 +439,29 @@ def run_config(cfg, args, rank, local_rank, world, stat_dev, dist, brief):
         shade_flops = (120.0 + 40.0 * scene.desc.n_lights) * cnt["shades"] + 20.0 * cnt["tex_evals"]
         first_flops = (36.0 * first_inst + (30.0 * cnt["sphere_tests"] + 12.0 * cnt["plane_tests"]) * tc_rays
                        / max(tc_rays + cnt["rays_shadow"], 1) + (24.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0))
+        # The first-phase kernels are reported one by one (their launch times are separate HIP-event timers); the work the
+        # counters tally for both together (instance tests, shade points, mesh hand-overs) is split by their shares of the rays
+        ps = cnt["rays_primary"] / all_rays if all_rays else 1.0
         if fused:
-            first = ("k_raygen_shade+k_trace_shade",
-                     ({"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
-                      # 12 B per path (radiance slot cleared), 64 B per secondary ray read, 80 B per ray handed to the mesh phase
-                      # (64 B entry + 16 B work item), and this share of the shade points' outputs
-                      12.0 * cnt["paths"] + 64.0 * cnt["rays_secondary"] + 80.0 * cnt["mesh_items"] + (1.0 - mesh_frac) * shade_out_bytes,
-                      first_flops + (1.0 - mesh_frac) * shade_flops, "k_raygen_shade<false"))
+            rest_b = 80.0 * cnt["mesh_items"] + (1.0 - mesh_frac) * shade_out_bytes
+            rest_f = first_flops + (1.0 - mesh_frac) * shade_flops
+            first = [("k_raygen_shade", (prof["raygen"],
+                      # 12 B per path (radiance slot cleared), 80 B per ray handed to the mesh phase (64 B entry + 16 B work item),
+                      # and this share of the shade points' outputs
+                      12.0 * cnt["paths"] + ps * rest_b, ps * rest_f, "k_raygen_shade<false")),
+                     ("k_trace_shade", (prof["trace_closest"],
+                      # 64 B per secondary ray read
+                      64.0 * cnt["rays_secondary"] + (1.0 - ps) * rest_b, (1.0 - ps) * rest_f, "k_trace_shade<false"))]
         else:
-            first = ("k_raygen_trace+k_trace_closest",
-                     ({"ms": prof["raygen"]["ms"] + prof["trace_closest"]["ms"], "launches": prof["raygen"]["launches"]},
-                      # camera rays: 80 B written per path, generated and traced in registers; secondary rays 48 B; the instance
-                      # BVH's boxes count when it is used
-                      80.0 * cnt["paths"] + 48.0 * cnt["rays_secondary"] + (32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0),
-                      first_flops, "k_raygen_trace<false"))
+            tlas_b = 32.0 * cnt["closest_node_visits"] if cnt["mesh_items"] == 0 else 0.0
+            first = [("k_raygen_trace", (prof["raygen"],
+                      # camera rays: 80 B written per path, generated and traced in registers; the instance BVH's boxes count when it is used
+                      80.0 * cnt["paths"] + ps * tlas_b, ps * first_flops, "k_raygen_trace<false")),
+                     ("k_trace_closest", (prof["trace_closest"], 48.0 * cnt["rays_secondary"] + (1.0 - ps) * tlas_b,
+                      (1.0 - ps) * first_flops, "k_trace_closest<false"))]
         kern = {
-            first[0]: first[1],
+            first[0][0]: first[0][1],
+            first[1][0]: first[1][1],
             "k_trace_mesh": (prof["trace_mesh"],
                              48.0 * cnt["mesh_items"] + 32.0 * cnt["closest_node_visits"] + 48.0 * cnt["closest_tri_tests"],
                              36.0 * cnt["mesh_inst_tests"] + 24.0 * cnt["closest_node_visits"] + 51.0 * cnt["closest_tri_tests"],

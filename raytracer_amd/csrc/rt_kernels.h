@@ -1327,6 +1327,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   W.p = W.d = W.inv = v3(0, 0, 0);
   W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
   W.hint = 0; W.onpath = false; W.minst = RT_NONE;
+#ifdef RT_SM_STATS   // developer build: node steps of the rays that end lit / occluded (scripts/dev/sm_stats.sh)
+  uint32_t my_steps = 0; unsigned long long st_lit = 0, st_occ = 0, n_lit = 0, n_occ = 0;
+#endif
   for (;;) {  // one wave-wide step per iteration, as in k_trace_mesh
     if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); W.onpath = false; }
     if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) state = RT_ST_NEXT;
@@ -1342,6 +1345,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
       if (state == RT_ST_NEXT) {
         enter = W.next;
         if (enter == RT_NONE) {
+#ifdef RT_SM_STATS
+          st_lit += my_steps; n_lit++; my_steps = 0;
+#endif
           if (SOFT) {
             rt_atomic_add_u32((uint32_t*)&G.g2[group].z, 1u);
           } else {
@@ -1382,6 +1388,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
           float4 n0, n1, n2, n3;
           fetch_node(S, W, true, n0, n1, n2, n3);
           mesh_walk_node<CNT, RT_SHADOW_ORDERED != 0, HINT>(W, n0, n1, n2, n3, tmax, stk, stride, cnt);
+#ifdef RT_SM_STATS
+          my_steps++;
+#endif
         }
       }
     } else if (walking && W.pend != 0) {
@@ -1390,6 +1399,9 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
       W.pend = 0;
       if (occluded) {
         state = RT_ST_IDLE;
+#ifdef RT_SM_STATS
+        st_occ += my_steps; n_occ++; my_steps = 0;
+#endif
         if (HINT && (hint_minst != W.minst || hint_slot != at_slot)) {
           hint_minst = W.minst; hint_slot = at_slot;
           if (SOFT) { uint2 gh; gh.x = hint_minst; gh.y = hint_slot; G.hint[group] = gh; }
@@ -1397,6 +1409,12 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
       }
     }
   }
+#ifdef RT_SM_STATS
+  if (CNT) {
+    rt_atomic_add_u64(&F.counters->photon_visits, st_lit); rt_atomic_add_u64(&F.counters->gathers, st_occ);
+    rt_atomic_add_u64(&F.counters->tex_evals, n_lit); rt_atomic_add_u64(&F.counters->shades, n_occ);
+  }
+#endif
   if (CNT) cnt.flush(F.counters);
 }
 
