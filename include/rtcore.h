@@ -379,9 +379,13 @@ int rt_profile_get(rt_context* ctx, rt_profile* out);
  * "gather_hints" (0: every photon lookup from scratch), "frame_gb" (stage-queue memory of one pass), "fan_scale" (scales the
  * measured queue sizing; tests force the overflow path with it), "timing", "soft_clear" (0: every soft-shadow group is traced;
  * 1, the default: groups with a proven clear view of their light, or proven to lie in a sphere's full shadow, are finished
- * without their rays — the same frame either way, rt_counters.rays_shadow_proven counts what was saved).  Their initial values
+ * without their rays — the same frame either way, rt_counters.rays_shadow_proven counts what was saved), "cone_max_inst"
+ * (instances up to which those proofs walk the instance table; beyond it the instance BVH), "shadow_tlas_min" (instances from
+ * which shadow rays walk the instance BVH; next commit), "fuse" (1: first trace phase and shading of the rays it finishes in
+ * one kernel), "shadow_hints" (soft-shadow rays head for the triangle that blocked their group's previous ray first: 1 on,
+ * 0 off, -1 — the default — by the depth of the scene's mesh trees; the same frame either way).  Their initial values
  * come from the environment variables RT_TLAS_MIN / RT_GATHER_HINTS / RT_FRAME_GB / RT_TEST_FAN_SCALE / RT_TIMING /
- * RT_SOFT_CLEAR, read once by rt_context_create. */
+ * RT_SOFT_CLEAR / RT_SHADOW_HINTS, read once by rt_context_create. */
 int rt_set_option(rt_context* ctx, const char* name, double value);
 /* Number of device allocations (hipMalloc) made so far on behalf of this context: the entry points keep their device
  * buffers in the context and grow them only, so a steady-state caller sees this stand still (no counterpart in the

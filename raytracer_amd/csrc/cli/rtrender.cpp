@@ -15,7 +15,8 @@ static void usage() {
   std::fprintf(stderr,
                "usage: rtrender scene.xml [--out raw.png] [--denoised out.png] [--zbuffer z.png] [--samples n.png] [--width W --height H]\n"
                "                [--spp N | --spp-min A --spp-max B]\n"
-               "                [--bounces N] [--mc-bounces N] [--no-photons] [--no-jitter] [--seed S] [--device D] [--assets DIR]\n");
+               "                [--bounces N] [--mc-bounces N] [--no-photons] [--no-jitter] [--seed S] [--device D] [--assets DIR]\n"
+               "                [--extensions BITS]   1: real Phong / microfacet materials, 2: filtered texture lookups (ray differentials)\n");
 }
 
 int main(int argc, char** argv) {
@@ -42,6 +43,7 @@ int main(int argc, char** argv) {
     else if (arg("--seed")) P.seed_lo = (uint32_t)std::strtoul(argv[++i], nullptr, 10);
     else if (arg("--device")) device = std::atoi(argv[++i]);
     else if (arg("--assets")) assets = argv[++i];
+    else if (arg("--extensions")) P.extensions = (uint32_t)std::strtoul(argv[++i], nullptr, 10);   // RT_EXT_* bits
     else if (!std::strcmp(argv[i], "--no-photons")) P.photons = 0;
     else if (!std::strcmp(argv[i], "--no-jitter")) P.pixel_jitter = 0;
     else { usage(); return 2; }
