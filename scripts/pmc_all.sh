@@ -7,7 +7,7 @@ export BENCH_CONFIG=${2:-c2}
 bash scripts/pmc_traffic.sh ${R}_pmc_${BENCH_CONFIG} > /dev/null || exit 1
 cp gpurun_out/${R}_pmc_${BENCH_CONFIG}/summary.json gpurun_out/${R}_pmc_summary_${BENCH_CONFIG}.json
 mkdir -p profiles && cp gpurun_out/${R}_pmc_summary_${BENCH_CONFIG}.json profiles/${R}_pmc_summary_${BENCH_CONFIG}.json
-timeout -k 10 400 python3 bench.py --config ${BENCH_CONFIG} ${BENCH_ARGS:-} > gpurun_out/${R}_bench_${BENCH_CONFIG}.json 2> gpurun_out/${R}_bench_${BENCH_CONFIG}.err || { tail -20 gpurun_out/${R}_bench_${BENCH_CONFIG}.err; exit 1; }
+timeout -k 10 400 python3 bench.py --config ${BENCH_CONFIG} --no-other-configs ${BENCH_ARGS:-} > gpurun_out/${R}_bench_${BENCH_CONFIG}.json 2> gpurun_out/${R}_bench_${BENCH_CONFIG}.err || { tail -20 gpurun_out/${R}_bench_${BENCH_CONFIG}.err; exit 1; }
 python3 - <<PY
 import json
 d = json.load(open("gpurun_out/${R}_bench_${BENCH_CONFIG}.json"))
