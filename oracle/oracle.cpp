@@ -1779,7 +1779,11 @@ void primary_differentials(const orc_scene& S, const rt_render_params& P, const 
         }
       }
     }
-    hit.duvw[a] = uv2 - uvw;
+    V dd = uv2 - uvw;   // held to 64 tiles per pixel, NaN included (rt_device.h: RT_DUVW_MAX)
+    dd.x = fminf(fmaxf(dd.x, -64.0f), 64.0f);
+    dd.y = fminf(fmaxf(dd.y, -64.0f), 64.0f);
+    dd.z = fminf(fmaxf(dd.z, -64.0f), 64.0f);
+    hit.duvw[a] = dd;
   }
   hit.filtered = true;
 }

@@ -147,6 +147,7 @@ struct DScene {
 #define RT_HPHI 512
 #define RT_HTHETA 1512
 #define RT_HGLOSS 2512
+#define RT_DUVW_MAX 64.0f   // largest texture-coordinate derivative per pixel that hit_differentials hands on
 #define RT_FILTER_TAPS 32   // Texture::Eval(uvw, duvw): sampleCount (scene.h:293); offsets behind the gloss tables: x[32], y[32]
 
 struct DCounters {  // mirrors rt_counters
@@ -1714,7 +1715,14 @@ RT_DEV void hit_differentials(const DScene& S, const DShadeInst& I, V3 o, V3 dir
         uv2 = (v3(f0.w, f1.w, f2.w) * w) + (v3(f3.x, f3.y, f3.z) * u) + (v3(f3.w, f4.x, f4.y) * v);
       }
     }
-    if (a) du1 = uv2 - uvw; else du0 = uv2 - uvw;
+    // A ray that grazes the surface meets its local approximation arbitrarily far away: the derivative is held to
+    // RT_DUVW_MAX texture tiles per pixel (a footprint that size averages the texture anyway, and the taps' coordinates
+    // stay where tile_clamp's integer part is defined); a NaN (a degenerate approximation) becomes the limit as well.
+    V3 dd = uv2 - uvw;
+    dd.x = fminf(fmaxf(dd.x, -RT_DUVW_MAX), RT_DUVW_MAX);
+    dd.y = fminf(fmaxf(dd.y, -RT_DUVW_MAX), RT_DUVW_MAX);
+    dd.z = fminf(fmaxf(dd.z, -RT_DUVW_MAX), RT_DUVW_MAX);
+    if (a) du1 = dd; else du0 = dd;
   }
 }
 

@@ -321,6 +321,15 @@ def check_texture_filter(r, w=160, h=90, ref_spp=64):
     q1.extensions = RT_EXT_TEX_FILTER
     a, b = r.Render(q0), r.Render(q1)
     assert np.array_equal(a.hit_node, b.hit_node) and np.allclose(a.radiance, b.radiance, rtol=1e-6, atol=1e-7)
+    # a camera that skims the floor: the neighbouring pixels' rays meet the plane arbitrarily far away (derivatives held to
+    # RT_DUVW_MAX), some not at all; the frame still agrees with the oracle
+    low = Scene.from_string(TEXFILTER.replace('<position x="0" y="-20" z="4"/> <target x="0" y="10" z="2"/>',
+                                              '<position x="0" y="-20" z="0.02"/> <target x="0" y="10" z="0.02"/>'), asset_dir=ROOT)
+    r.LoadScene(low)
+    gl, cl = r.Render(p1), oracle_ffi.OracleScene(low).render(p1)
+    assert np.array_equal(gl.hit_node, cl.hit_node) and np.isfinite(gl.radiance).all() and np.isfinite(cl.radiance).all()
+    dl = np.abs(gl.radiance[..., :3] - cl.radiance[..., :3]) / np.maximum(np.abs(cl.radiance[..., :3]), 1e-3)
+    assert (dl.max(axis=-1) <= 1e-4).mean() >= 0.995 and psnr8(gl.img, cl.img) >= 50.0, ((dl.max(axis=-1) <= 1e-4).mean(), psnr8(gl.img, cl.img))
     # stochastic frame with bounces on the textured scene: camera hits filtered, secondary hits not
     r.LoadScene(scene)
     s1 = params(w, h, spp=2, jitter=1, bounces=2)
