@@ -94,6 +94,8 @@ def test_shadow_hints_change_the_walk_only(emu):
     assert on < off   # fewer node visits to the same answers
     bare = Scene.stress(seed=7, n_instances=24, subdiv=3, ground_res=96, width=160, height=90, host_bvh=False)
     common_checks.check_shadow_hints(emu, bare, 48, 27, device_bvh=True)   # the device-built tree names its slot ranges too
+    # several mesh instances under one sized light: a hint only steers the walk of the instance it was found in
+    common_checks.check_shadow_hints(emu, common_checks.load_multimtl_scene(), 80, 45, tol=1e-4)
 
 
 def test_soft_shadow_clear_view_shortcut(emu):

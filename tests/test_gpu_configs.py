@@ -66,6 +66,7 @@ def test_shadow_hints_change_the_walk_only(gpu_renderer):
     assert on < off
     bare = Scene.stress(seed=7, n_instances=96, subdiv=3, ground_res=230, width=480, height=270, host_bvh=False)
     cc.check_shadow_hints(gpu_renderer, bare, 160, 90, device_bvh=True)
+    cc.check_shadow_hints(gpu_renderer, cc.load_multimtl_scene(), 160, 90, spp=2, tol=1e-4)   # six mesh instances, one sized light
 
 
 def test_soft_shadow_clear_view_shortcut(gpu_renderer):
