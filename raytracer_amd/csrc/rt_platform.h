@@ -58,6 +58,7 @@ static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n 
 static inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return 0; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }

@@ -127,6 +127,7 @@ struct Options {
                                    //                                  0: the separate k_raygen_trace / k_trace_closest / k_shade launches
   double shadow_hints = -1;        // "shadow_hints" RT_SHADOW_HINTS   soft-shadow mesh walks head for the previous ray's occluder first: 1 on, 0 off,
                                    //                                  -1 by the depth of the scene's mesh trees (>= RT_SHADOW_HINT_DEPTH)
+  double summary_mapped = 1;       // "summary_mapped" RT_SUMMARY_MAPPED  1: the per-pass summary is written into pinned host memory by the kernel itself
   double cone_max_inst = RT_CONE_MAX_INST;   // "cone_max_inst"  instances up to which the soft-shadow proofs walk the instance table; beyond it
                                              //                  (with an instance BVH) every group's cone walks the BVH (tests force both)
 };
@@ -176,6 +177,7 @@ struct rt_context {
   uint32_t* d_counts = nullptr;  // [levels][8] + overflow + misc
   uint32_t* d_summary = nullptr; // k_pass_summary's output (allocated with the context)
   uint32_t* h_summary = nullptr; // ... and its pinned host copy
+  uint32_t* h_summary_dev = nullptr;  // the device's address of that pinned page, when the kernel can write it directly (no copy)
   float* d_path_rad = nullptr;      // three planes of rad_stride floats
   uint32_t rad_stride = 0;
   uint32_t* d_pixels = nullptr;
@@ -609,6 +611,9 @@ int rt_context_create(int device_id, rt_context** out) {
     ctx->d_summary = (uint32_t*)ds;
     if (hipHostMalloc(&hs, 4096) != hipSuccess) return fail_create();
     ctx->h_summary = (uint32_t*)hs;
+    void* hd = nullptr;   // page-locked host memory is mapped into the device's address space: the summary kernel writes it in place
+    if (const char* e = std::getenv("RT_SUMMARY_MAPPED")) ctx->opt.summary_mapped = std::atof(e);   // (A/B knob: 0 = copy it)
+    if (ctx->opt.summary_mapped != 0 && hipHostGetDevicePointer(&hd, hs, 0) == hipSuccess && hd) ctx->h_summary_dev = (uint32_t*)hd;
   }
   {  // this device's address of the no-allocation entry point's working array (the device is current: hipSetDevice above)
 #ifndef RT_EMU
@@ -2138,8 +2143,11 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   auto finish_pass = [&](uint64_t paths) -> int {
     // the pass in 1 KB: per (level, kind) the sum and the maximum of the segment lengths + the overflow word, folded on the
     // device and copied into pinned host memory (the full table of counters is 1 MB; copying it cost more than a C1 frame)
-    LAUNCH(k_pass_summary, N_SLOTS, (const uint32_t*)ctx->d_counts, N_SLOTS, NSEG, (uint32_t)CNT_SLAB, (uint32_t)CNT_OVERFLOW, ctx->d_summary);
-    HIP_TRY(hipMemcpyAsync(ctx->h_summary, ctx->d_summary, (2 * N_SLOTS + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // (written straight into the pinned page where the device can address it: a 1 KB copy is a launch of its own, 12 - 20 us,
+    //  a tenth of a C1 step)
+    uint32_t* const summary_out = ctx->h_summary_dev ? ctx->h_summary_dev : ctx->d_summary;
+    LAUNCH(k_pass_summary, N_SLOTS, (const uint32_t*)ctx->d_counts, N_SLOTS, NSEG, (uint32_t)CNT_SLAB, (uint32_t)CNT_OVERFLOW, summary_out);
+    if (!ctx->h_summary_dev) HIP_TRY(hipMemcpyAsync(ctx->h_summary, ctx->d_summary, (2 * N_SLOTS + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
     const uint32_t* sums = ctx->h_summary;
