@@ -211,6 +211,11 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 // eligible photon beyond the k-th distance decides the exception.  The photon SET is the reference's (equal d' values
 // among different photons are resolved by visiting order here and by heap history there); the power sum runs in
 // visiting order instead of heap order, i.e. irradiance agrees to float-sum reordering (tests: 2e-5 relative).
+#ifndef RT_GATHER_STATS
+#define RT_GATHER_STATS 0   // developer tallies (scripts/dev/gather_stats.sh): photon_visits counts one kind of walk only — 1 the hinted
+#endif                      // collecting walk, 2 the exception / tie walks, 3 counting walks, 4 the collecting walk after them; 5: gathers = stage-2 lookups; 6 / 7: hinted collecting / counting walks over the full radius
+#define RT_GS_V(kind) (RT_GATHER_STATS == 0 || RT_GATHER_STATS == 5 || RT_GATHER_STATS == (kind) || RT_GATHER_STATS == 10 + (kind) ? visits : gs_dummy)
+#define RT_GS_LONG 2000   // 11..14: kinds 1..4 again, but only the walks of more than this many visits
 struct HeapMem {     // per-lane views of the lookup's LDS: entry i of this lane is at [i * stride]
   uint32_t* walk;    // kd walk stack: node index << 4 | split axis << 2 | state (pre-order walks: the node index alone)
   uint32_t* list;    // RT_SEL entries: the collecting walk's bracket photons in visiting order
@@ -230,7 +235,7 @@ RT_DEV V3 photon_power_raw(float4 pa, float4 pb) {  // 255 x GetPower: the divis
 // Visits, in LocatePhotons' order, every photon of the kd-tree that is eligible under the FIXED squared radius `bound`
 // and calls f(d', index, pa, pb); f returns true to stop the walk.  One `visits` per node entered (photonmap.h:340).
 template <class F>
-RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
+RT_DEV void photon_walk_impl(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
   const uint32_t hs = hm.stride;
   int sp = 0;
   uint32_t index = 1;
@@ -311,9 +316,13 @@ RT_DEV bool photon_eligible(float4 pa, float4 pb, V3 pos, V3 normal, float normS
 // The same set of photons in pre-order (node, nearer child, farther child): with a FIXED radius the decision to enter
 // the farther child does not depend on what the nearer subtree held, so a node is fetched once and the stack holds
 // nothing but the farther children still to enter.  For the counting / collecting walks, whose results do not depend on
-// the order.
+// the order.  f returns the squared radius to go on with: the same, a smaller one (what was found so far makes the rest of
+// the larger ball irrelevant; nodes already on the stack are still entered, under the new radius), or a negative value
+// to stop at once.  Without this a lookup whose starting radius suits a sparser place than the one it is at — a stale hint
+// at the edge of a caustic, the default first guess inside one — walks every photon of that ball: tens of thousands of
+// dependent fetches on one lane, milliseconds for the whole launch.
 template <class F>
-RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
+RT_DEV void photon_walk_pre_impl(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
   const uint32_t hs = hm.stride;
   int sp = 0;
   uint32_t index = 1;
@@ -337,11 +346,35 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
       nb = M.ph[2 * (size_t)next + 1];
     }
     float dist2;
-    if (photon_eligible(pa, pb, pos, normal, normScale, bound, dist2)) f(dist2, index, pa, pb);
+    if (photon_eligible(pa, pb, pos, normal, normScale, bound, dist2)) {
+      bound = f(dist2, index, pa, pb);
+      if (bound < 0.0f) return;
+    }
     if (next == 0) return;
     index = next;
     pa = na; pb = nb;
   }
+}
+
+template <class F>
+RT_DEV void photon_walk(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
+#if RT_GATHER_STATS >= 10
+  uint32_t v = 0;
+  photon_walk_impl(M, pos, normal, normScale, bound, hm, v, f);
+  if (v > RT_GS_LONG) visits += v;
+#else
+  photon_walk_impl(M, pos, normal, normScale, bound, hm, visits, f);
+#endif
+}
+template <class F>
+RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float bound, const HeapMem& hm, uint32_t& visits, F&& f) {
+#if RT_GATHER_STATS >= 10
+  uint32_t v = 0;
+  photon_walk_pre_impl(M, pos, normal, normScale, bound, hm, v, f);
+  if (v > RT_GS_LONG) visits += v;
+#else
+  photon_walk_pre_impl(M, pos, normal, normScale, bound, hm, visits, f);
+#endif
 }
 
 #ifndef RT_TEST_NO_EVICT_RULE
@@ -365,9 +398,11 @@ struct Collected {
 
 // SORT_WIDE false: a bracket of more than RT_SEL photons is only counted (the hinted lookup rejects it afterwards), which
 // keeps the sorted list out of the walk's registers.
+// `give_up`: the walk stops as soon as more photons than that lie below the bracket (the hinted lookup's bracket is then
+// too high, whatever else the ball holds).
 template <bool SORT_WIDE>
-RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float lo, float hi, const HeapMem& hm, uint32_t& visits,
-                           Collected& C) {
+RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float lo, float hi, uint32_t give_up, const HeapMem& hm,
+                           uint32_t& visits, Collected& C) {
 #pragma unroll
   for (int i = 0; i < RT_SEL; i++) { C.ed[i] = RT_BIG; C.ei[i] = 0; }
   C.raw = v3(0, 0, 0);
@@ -396,10 +431,10 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
       C.n_below++;
       C.raw = C.raw + photon_power_raw(pa, pb);
       if (d2 > C.max_d) { C.max_d = d2; C.max_i = index; }
-      return;
+      return C.n_below > give_up ? -1.0f : hi;
     }
-    if (n_list < RT_SEL) { hm.list[(n_list++) * hs] = index; return; }
-    if (!SORT_WIDE) return;
+    if (n_list < RT_SEL) { hm.list[(n_list++) * hs] = index; return hi; }
+    if (!SORT_WIDE) return hi;
     if (!spilled) {   // the list is full: sort what it holds, then carry on sorting in place
       spilled = true;
       for (uint32_t i = 0; i < RT_SEL; i++) {
@@ -411,6 +446,7 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
       }
     }
     insert_sorted(d2, index);
+    return hi;
   });
   if (!spilled) {
     for (uint32_t i = 0; i < RT_SEL; i++) {
@@ -429,6 +465,7 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
 RT_DEV V3 photon_finish(const DPhotonMap& M, V3 pos, V3 normal, float normScale, float r2, uint32_t K, bool all, const HeapMem& hm,
                         uint32_t& visits, const Collected& C, float& guess, float& hint) {
   if (C.n_all == 0) { hint = r2; return v3(0, 0, 0); }
+  uint32_t gs_dummy = 0; (void)gs_dummy;
   V3 sum = C.raw / 255.0f;
   float bound, next_hint;
   if (all) {  // |U| <= k: everything was summed (lo = radius^2), area from the search radius (dist2[0] never changes)
@@ -448,8 +485,9 @@ RT_DEV V3 photon_finish(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
       // every one of them).  No exception test: it needs the k-th distance exactly.
       uint32_t need = K - C.n_below, taken = 0;
       V3 extra = v3(0, 0, 0);
-      photon_walk_pre(M, pos, normal, normScale, C.hi, hm, visits, [&](float d2, uint32_t, float4 pa, float4 pb) {
+      photon_walk_pre(M, pos, normal, normScale, C.hi, hm, RT_GS_V(2), [&](float d2, uint32_t, float4 pa, float4 pb) {
         if (d2 >= C.lo && taken < need) { extra = extra + photon_power(pa, pb); taken++; }
+        return C.hi;
       });
       sum = sum + extra;
       guess = C.hi * 1.25f;
@@ -472,7 +510,7 @@ RT_DEV V3 photon_finish(const DPhotonMap& M, V3 pos, V3 normal, float normScale,
       // the exception: the first k eligible photons in visiting order are the k nearest (none beyond the k-th distance)
       uint32_t seen = 0;
       bool beyond = false;
-      photon_walk(M, pos, normal, normScale, r2, hm, visits, [&](float d2, uint32_t, float4, float4) {
+      photon_walk(M, pos, normal, normScale, r2, hm, RT_GS_V(2), [&](float d2, uint32_t, float4, float4) {
         if (d2 > d_k) { beyond = true; return true; }
         return ++seen == K;
       });
@@ -499,6 +537,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
   const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
+  uint32_t gs_dummy = 0; (void)gs_dummy;
   // ---- bracket [lo, hi) of the (k+1)-th smallest d': C(lo) <= k and C(hi) >= k + 1, C(t) = #{eligible, d' < t}
   // (a guess far below the radius — the lane's previous lookup sat in a dense cluster — is raised to a floor: every step
   // up from it costs a walk)
@@ -518,10 +557,23 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
     for (int i = 0; i < RT_SEL; i++) { t[i] = lo + step * (float)(i + 1); c[i] = 0; }
     t[RT_SEL - 1] = hi;
     uint32_t below = 0;
-    photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t, float4, float4) {
-      if (d2 < lo) { below++; return; }
+    float wb = hi;   // the walk's radius, shrinking
+    photon_walk_pre(M, pos, normal, normScale, hi, hm, RT_GATHER_STATS == 7 && hi == r2 ? visits : RT_GS_V(3), [&](float d2, uint32_t, float4, float4) {
+      if (d2 >= lo) {
 #pragma unroll
-      for (int i = 0; i < RT_SEL; i++) c[i] += d2 < t[i] ? 1u : 0u;
+        for (int i = 0; i < RT_SEL; i++) c[i] += d2 < t[i] ? 1u : 0u;
+      } else {
+        below++;
+      }
+      // more than k photons below one of the lower thresholds already: the (k+1)-th smallest d' lies below it, and the
+      // rest of the walk only has to complete the counts up to there (the counts above it stay incomplete and unused:
+      // the narrowing below picks the lowest threshold with more than k, which is this one or a lower one)
+      float go_on = wb;
+      if (below + c[RT_SEL / 2 - 1] > K) go_on = fminf(go_on, t[RT_SEL / 2 - 1]);
+      if (below + c[RT_SEL / 4 - 1] > K) go_on = fminf(go_on, t[RT_SEL / 4 - 1]);
+      if (below + c[0] > K) go_on = fminf(go_on, t[0]);
+      wb = go_on;
+      return go_on;
     });
     c_lo = below;
     c_hi = below + c[RT_SEL - 1];
@@ -550,7 +602,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
   }
   // ---- collect: powers below the bracket, the bracket's photons sorted by d' (ties in visiting order)
   Collected C;
-  photon_collect<true>(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  photon_collect<true>(M, pos, normal, normScale, lo, hi, 0xffffffffu, hm, RT_GS_V(4), C);
   return photon_finish(M, pos, normal, normScale, r2, K, all, hm, visits, C, guess, hint);
 }
 
@@ -575,10 +627,16 @@ RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float
     hi = hint * (1.0f + delta);
   }
   Collected C;
-  photon_collect<false>(M, pos, normal, normScale, lo, hi, hm, visits, C);
+  uint32_t gs_dummy = 0; (void)gs_dummy;
+  photon_collect<false>(M, pos, normal, normScale, lo, hi, K, hm, RT_GATHER_STATS == 6 && hi == r2 ? visits : RT_GS_V(1), C);
+  if (RT_GATHER_STATS == 8 && hi == r2) visits += 1u;          // 8: the number of such walks, 9: of those that find more than k photons
+  if (RT_GATHER_STATS == 9 && hi == r2 && C.n_all > K) visits += 1u;
   bool all = false;
+  if (C.n_below > K) {   // (the walk gave up there) the answer lies below lo
+    hint = -(hi == r2 ? 0.5f * r2 : lo);
+    return false;
+  }
   if (hi == r2) {
-    if (C.n_all > K) { hint = -0.5f * r2; return false; }
     all = true;
   } else if (!(C.n_below <= K && C.n_all >= K + 1 && C.n_all - C.n_below <= RT_SEL)) {
     // what this walk saw seeds the counting walks: the answer lies below hi, or above it
@@ -732,7 +790,7 @@ RT_KERNEL_W(RT_GATHER_WAVES, k_photon_gather, GatherP G, FrameBufs F, GatherQ Q)
         todo = false;
       }
       if (!todo) {
-        if (M.stored > 0) gathers++;
+        if (M.stored > 0 && (RT_GATHER_STATS != 5 || STAGE == 2)) gathers++;
         add_radiance(F, __float_as_uint(a.w), v3(c.x, c.y, c.z) * E);
       }
     }

@@ -1838,6 +1838,7 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     t.stop((1ull << 32) + n0);
   }
   double ub = n0;
+  uint64_t gather_ub = 0;
   int branch = 2 + (P.mc_bounces > 0 ? 1 : 0);
   const uint64_t qcap = (uint64_t)Qc.segcap * Qc.nseg;
   for (int lvl = 0; lvl < levels; lvl++) {
@@ -1846,7 +1847,9 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     GatherQ GQ = ctx->GQ;
     GH.counts = ctx->d_counts + cnt_at(lvl, CNT_GH);
     GS.counts = ctx->d_counts + cnt_at(lvl, CNT_GS);
-    GQ.counts = ctx->d_counts + cnt_at(lvl, CNT_GQ);
+    // ONE lookup queue for the pass: every level appends to it and it is served once, after the last level.  A launch of the
+    // gather is as long as its longest lookup (a chain of dependent fetches), so four small launches cost four such tails.
+    GQ.counts = ctx->d_counts + cnt_at(0, CNT_GQ);
     uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
     if (fuse) {
@@ -1988,13 +1991,16 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
     }
-    if (photons) {
-      Timer t(ctx, RT_K_PHOTON_GATHER);
-      photon_gather_queue<CNT>(ctx, GQ, F, P, RP, ubn, ctx->d_counts + cnt_at(lvl, CNT_GR));
-      t.stop((uint64_t)(lvl * CNT_KINDS + CNT_GQ));
-    }
+    gather_ub += ubn;
     std::swap(Qc, Qn);
     ub *= branch;
+  }
+  if (photons) {
+    GatherQ GQ = ctx->GQ;
+    GQ.counts = ctx->d_counts + cnt_at(0, CNT_GQ);
+    Timer t(ctx, RT_K_PHOTON_GATHER);
+    photon_gather_queue<CNT>(ctx, GQ, F, P, RP, std::min<uint64_t>(gather_ub, (uint64_t)GQ.segcap * GQ.nseg), ctx->d_counts + cnt_at(0, CNT_GR));
+    t.stop((uint64_t)CNT_GQ);
   }
   if (photons && !P.discard) ctx->gather_hints_cold = false;   // (a sizing pass covers a pixel subset only)
   {
@@ -2051,7 +2057,9 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   const bool meshes = ctx->n_minst > 0;
   const double soft_rays = std::max<int>(RP.shadow_min, std::min<int>(RP.shadow_max - RP.shadow_min, RT_SOFT_CHUNK));   // mesh-phase items of one launch
   const double nmi = std::max(1, ctx->n_minst);   // candidates per item: at most every mesh instance
-  const double fworst[NFAN] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst : 0.0,
+  double worst_sum = 0.0;   // the photon lookups of all levels share one queue
+  for (int l = 0; l < fp.levels; l++) worst_sum += std::pow((double)fp.branch, l);
+  const double fworst[NFAN] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst_sum : 0.0,
                             meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0,
                             meshes ? worst * nmi : 0.0, meshes ? worst * n_hard * nmi : 0.0, meshes ? worst * n_soft * soft_rays * nmi : 0.0};
   auto per_path_bytes = [&](const double* f) {
