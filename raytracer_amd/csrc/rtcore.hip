@@ -1845,12 +1845,14 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
     Qn.counts = ctx->d_counts + cnt_at(lvl + 1, CNT_Q);
     GroupQ GH = ctx->GH, GS = ctx->GS;
     GatherQ GQ = ctx->GQ;
-    GH.counts = ctx->d_counts + cnt_at(lvl, CNT_GH);
-    GS.counts = ctx->d_counts + cnt_at(lvl, CNT_GS);
+    // ONE set of shadow-group queues for the pass, too: every level appends, the shadow stage runs once after the last level
+    // (it only adds radiance to the paths).  A scene's deeper levels hold few groups, and a launch of the two-phase shadow
+    // kernels is never shorter than its longest walk: finalProject spent 7.6 of 31 ms in the small launches of levels 1 - 3.
+    GH.counts = ctx->d_counts + cnt_at(0, CNT_GH);
+    GS.counts = ctx->d_counts + cnt_at(0, CNT_GS);
     // ONE lookup queue for the pass: every level appends to it and it is served once, after the last level.  A launch of the
     // gather is as long as its longest lookup (a chain of dependent fetches), so four small launches cost four such tails.
     GQ.counts = ctx->d_counts + cnt_at(0, CNT_GQ);
-    uint32_t* n2 = ctx->d_counts + cnt_at(lvl, CNT_N2);
     uint64_t ubn = (uint64_t)std::min<double>(ub, (double)qcap);
     if (fuse) {
       // first trace phase + shading of the rays it finishes in ONE kernel; the rays that reach a mesh box go through QM / MQ
@@ -1912,6 +1914,17 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
         t.stop((uint64_t)(lvl * CNT_KINDS + CNT_Q));
       }
     }
+    gather_ub += ubn;
+    std::swap(Qc, Qn);
+    ub *= branch;
+  }
+  {   // the shadow stage of the whole pass
+    const int lvl = 0;   // (the count slots of the one queue set)
+    GroupQ GH = ctx->GH, GS = ctx->GS;
+    GH.counts = ctx->d_counts + cnt_at(0, CNT_GH);
+    GS.counts = ctx->d_counts + cnt_at(0, CNT_GS);
+    uint32_t* n2 = ctx->d_counts + cnt_at(0, CNT_N2);
+    const uint64_t ubn = std::min<uint64_t>(gather_ub, 0xffffffffull);   // entries of all levels
     if (any_hard) {
       Timer t(ctx, RT_K_SHADOW);
       MeshQ MH = meshq(ctx->MH, lvl, CNT_MH, CUR_MH);
@@ -1991,9 +2004,6 @@ int run_pass(rt_context* ctx, const PassP& P, const FrameBufs& F, int levels, bo
         LAUNCH(k_shadow_soft_final, gs_ub, P, F, GS, (const uint32_t*)ctx->d_list2, (const uint32_t*)n2);
       }
     }
-    gather_ub += ubn;
-    std::swap(Qc, Qn);
-    ub *= branch;
   }
   if (photons) {
     GatherQ GQ = ctx->GQ;
@@ -2057,11 +2067,11 @@ int accumulate_internal(rt_context* ctx, const rt_render_params& RP, float* d_ac
   const bool meshes = ctx->n_minst > 0;
   const double soft_rays = std::max<int>(RP.shadow_min, std::min<int>(RP.shadow_max - RP.shadow_min, RT_SOFT_CHUNK));   // mesh-phase items of one launch
   const double nmi = std::max(1, ctx->n_minst);   // candidates per item: at most every mesh instance
-  double worst_sum = 0.0;   // the photon lookups of all levels share one queue
+  double worst_sum = 0.0;   // the shadow groups and the photon lookups of all levels share one queue each
   for (int l = 0; l < fp.levels; l++) worst_sum += std::pow((double)fp.branch, l);
-  const double fworst[NFAN] = {worst, worst * n_hard, worst * n_soft, photons_mixed ? worst_sum : 0.0,
-                            meshes ? worst : 0.0, meshes ? worst * n_hard : 0.0, meshes ? worst * n_soft * soft_rays : 0.0,
-                            meshes ? worst * nmi : 0.0, meshes ? worst * n_hard * nmi : 0.0, meshes ? worst * n_soft * soft_rays * nmi : 0.0};
+  const double fworst[NFAN] = {worst, worst_sum * n_hard, worst_sum * n_soft, photons_mixed ? worst_sum : 0.0,
+                            meshes ? worst : 0.0, meshes ? worst_sum * n_hard : 0.0, meshes ? worst_sum * n_soft * soft_rays : 0.0,
+                            meshes ? worst * nmi : 0.0, meshes ? worst_sum * n_hard * nmi : 0.0, meshes ? worst_sum * n_soft * soft_rays * nmi : 0.0};
   auto per_path_bytes = [&](const double* f) {
     return 2.0 * 132 * std::max(1.0, f[0]) + 32.0 * f[1] + 84.0 * f[2] + 48.0 * f[3] + 16.0 * (f[4] + f[5] + f[6]) +
            32.0 * (std::max(f[4], f[7]) + std::max(f[5], f[8]) + std::max(f[6], f[9])) + 16.0 + 64.0;
