@@ -340,13 +340,26 @@ RT_DEV void photon_walk_pre_impl(const DPhotonMap& M, V3 pos, V3 normal, float n
     }
     if (next == 0 && sp > 0) next = hm.walk[(--sp) * hs];
     // the next node's photon is requested before this one is looked at: the walk is a chain of dependent fetches
-    float4 na = pa, nb = pb;
-    if (next != 0) {
-      na = M.ph[2 * (size_t)next];
-      nb = M.ph[2 * (size_t)next + 1];
-    }
+    // (the last node requests itself again: an unconditional load is cheaper than a branch around it in every step)
+    const uint32_t fetch = next != 0 ? next : index;
+    const float4 na = M.ph[2 * (size_t)fetch];
+    const float4 nb = M.ph[2 * (size_t)fetch + 1];
+    // photon_eligible's tests, all evaluated and then combined: in a wave some lane passes each of them nearly always, so
+    // the nested branches only added the bookkeeping of their masks (same operations, same floats)
     float dist2;
-    if (photon_eligible(pa, pb, pos, normal, normScale, bound, dist2)) {
+    bool ok;
+    {
+      V3 dif = v3(pa.x, pa.y, pa.z) - pos;
+      const float d_eu = dot(dif, dif);
+      const float facing = dot(v3(pb.x, pb.y, pb.z), normal);
+      const float perp = dot(dif, normal);
+      dif = dif + normal * (perp * normScale);
+      const float d_el = dot(dif, dif);
+      ok = d_eu < bound && !(facing >= 0.0f);
+      dist2 = d_eu;
+      if (normScale > 0.0f) { ok = ok && !(d_el >= bound); dist2 = d_el; }
+    }
+    if (ok) {
       bound = f(dist2, index, pa, pb);
       if (bound < 0.0f) return;
     }
