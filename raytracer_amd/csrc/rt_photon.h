@@ -157,11 +157,18 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
         break;  // absorbed
       }
       V3 newC = (c * mult) / prob;
-      if (lobe & 1) {
-        int which = (prevLobe & (4 | 2)) ? 1 : 0;  // caustics map after a specular / transmission bounce
-        if (PP.accept[which]) {
-          uint32_t at = rt_atomic_add_u32(O.count + which, 1u);
-          if (at < PP.cap) {
+      {
+        // a diffuse bounce deposits: into the caustics map after a specular / transmission bounce.  The record slot comes from
+        // one atomic per wave and map (the lanes that deposit in this step are counted with a ballot): one atomic per deposit
+        // on the map's single counter is what made a batch that fills the denser map ten times over take 11 ms.
+        const int which = (prevLobe & (4 | 2)) ? 1 : 0;
+        const bool d0 = (lobe & 1) && which == 0 && PP.accept[0];
+        const bool d1 = (lobe & 1) && which == 1 && PP.accept[1];
+        uint32_t at = seg_push(d0, O.count, 0u, PP.cap, O.overflow);
+        const uint32_t at1 = seg_push(d1, O.count + 1, 0u, PP.cap, O.overflow);
+        if (d1) at = at1;
+        if (d0 || d1) {
+          if (at != RT_NONE) {
             float4 a, b;
             photon_pack(sp.P, -newDir, newC, a, b);
             O.rec[which][2 * (size_t)at] = a;
@@ -169,8 +176,6 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
             uint2 k;
             k.x = t; k.y = which ? n_dep[1] : n_dep[0];
             O.key[which][at] = k;
-          } else {
-            *O.overflow = 1u;
           }
           if (which) n_dep[1]++; else n_dep[0]++;
         }
@@ -218,7 +223,7 @@ RT_KERNEL(k_photon_trace, DScene S, PhotonTraceP PP, PhotonOut O) {
 #define RT_GS_LONG 2000   // 11..14: kinds 1..4 again, but only the walks of more than this many visits
 struct HeapMem {     // per-lane views of the lookup's LDS: entry i of this lane is at [i * stride]
   uint32_t* walk;    // kd walk stack: node index << 4 | split axis << 2 | state (pre-order walks: the node index alone)
-  uint32_t* list;    // RT_SEL entries: the collecting walk's bracket photons in visiting order
+  uint32_t* list;    // RT_SEL entries: the first of the collecting walk's bracket photons, in visiting order
   uint32_t stride;
 };
 
@@ -394,9 +399,11 @@ RT_DEV void photon_walk_pre(const DPhotonMap& M, V3 pos, V3 normal, float normSc
 #define RT_TEST_NO_EVICT_RULE 0   // tests build a variant with 1 to prove that the exception below is exercised
 #endif
 #define RT_SEL 16   // thresholds per counting walk = photons kept sorted by the collecting walk
-#ifndef RT_HINT_HALF
-#define RT_HINT_HALF 4.0f   // half-width of a hinted bracket in photons; C4 gather with 2 / 3 / 3.5 / 4 / 5 / 6: 47.3 / 43.7 / 42.6 / 39.7 / 41.4 / 46.7 ms
-#endif
+#define RT_LIST 32  // photons of a bracket the collecting walk can note: RT_SEL in the lane's LDS list, the rest in private memory
+#ifndef RT_HINT_LO
+#define RT_HINT_LO 6.0f   // a hinted bracket reaches this many photons below the hint and RT_HINT_HI above it (in units of the hint /
+#define RT_HINT_HI 7.0f   // (k + 1)).  C4 step with (lo, hi) = (4,4) / (5,5) / (6,6) / (6,7) / (7,6) / (6,8) / (7.5,9) / (9,11): 30.0 / 29.1 /
+#endif                    // 29.0 / 28.6 / 28.7 / 29.0 / 29.4 / 31.2 ms (with the 16-entry list of round 2, +-4 was the best: wider overflowed it)
 
 // What the collecting walk over the bracket [lo, hi) leaves behind.
 struct Collected {
@@ -436,8 +443,9 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
   // are fetched again and sorted after the walk, all lanes together.  A bracket of more than RT_SEL photons (thresholds
   // that cannot separate equal d' values) keeps its RT_SEL smallest by sorting inside the walk, as before.
   uint32_t n_list = 0;
+  uint32_t more[RT_LIST - RT_SEL];   // entries RT_SEL .. RT_LIST - 1 of the list (private memory: written for the wider brackets only)
+  auto list_at = [&](uint32_t i) { return i < RT_SEL ? hm.list[i * hm.stride] : more[i - RT_SEL]; };
   bool spilled = false;
-  const uint32_t hs = hm.stride;
   photon_walk_pre(M, pos, normal, normScale, hi, hm, visits, [&](float d2, uint32_t index, float4 pa, float4 pb) {
     C.n_all++;
     if (d2 < lo) {
@@ -446,12 +454,16 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
       if (d2 > C.max_d) { C.max_d = d2; C.max_i = index; }
       return C.n_below > give_up ? -1.0f : hi;
     }
-    if (n_list < RT_SEL) { hm.list[(n_list++) * hs] = index; return hi; }
+    if (n_list < RT_LIST) {
+      if (n_list < RT_SEL) hm.list[n_list * hm.stride] = index; else more[n_list - RT_SEL] = index;
+      n_list++;
+      return hi;
+    }
     if (!SORT_WIDE) return hi;
     if (!spilled) {   // the list is full: sort what it holds, then carry on sorting in place
       spilled = true;
-      for (uint32_t i = 0; i < RT_SEL; i++) {
-        uint32_t pi = hm.list[i * hs];
+      for (uint32_t i = 0; i < RT_LIST; i++) {
+        uint32_t pi = list_at(i);
         float4 qa = M.ph[2 * (size_t)pi], qb = M.ph[2 * (size_t)pi + 1];
         float qd = 0.0f;
         (void)photon_eligible(qa, qb, pos, normal, normScale, hi, qd);
@@ -462,9 +474,9 @@ RT_DEV void photon_collect(const DPhotonMap& M, V3 pos, V3 normal, float normSca
     return hi;
   });
   if (!spilled) {
-    for (uint32_t i = 0; i < RT_SEL; i++) {
+    for (uint32_t i = 0; i < RT_LIST; i++) {
       if (i >= n_list) break;
-      uint32_t pi = hm.list[i * hs];
+      uint32_t pi = list_at(i);
       float4 qa = M.ph[2 * (size_t)pi], qb = M.ph[2 * (size_t)pi + 1];
       float qd = 0.0f;
       (void)photon_eligible(qa, qb, pos, normal, normScale, hi, qd);
@@ -551,6 +563,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
   uint32_t gs_dummy = 0; (void)gs_dummy;
+  if (RT_GATHER_STATS == 16) visits += 1u;
   // ---- bracket [lo, hi) of the (k+1)-th smallest d': C(lo) <= k and C(hi) >= k + 1, C(t) = #{eligible, d' < t}
   // (a guess far below the radius — the lane's previous lookup sat in a dense cluster — is raised to a floor: every step
   // up from it costs a walk)
@@ -570,6 +583,7 @@ RT_DEV V3 photon_estimate(const DPhotonMap& M, V3 pos, V3 normal, float radius, 
     for (int i = 0; i < RT_SEL; i++) { t[i] = lo + step * (float)(i + 1); c[i] = 0; }
     t[RT_SEL - 1] = hi;
     uint32_t below = 0;
+    if (RT_GATHER_STATS == 15) visits += 1u;   // 15: the number of counting walks; 16: of lookups from scratch
     float wb = hi;   // the walk's radius, shrinking
     photon_walk_pre(M, pos, normal, normScale, hi, hm, RT_GATHER_STATS == 7 && hi == r2 ? visits : RT_GS_V(3), [&](float d2, uint32_t, float4, float4) {
       if (d2 >= lo) {
@@ -631,13 +645,14 @@ RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float
   const float normScale = ellipticity == 1.0f ? 0.0f : 1.0f / ellipticity - 1.0f;
   const float r2 = radius * radius;
   const uint32_t K = (uint32_t)k;
-  const float delta = fminf(0.25f, RT_HINT_HALF / (float)(K + 1));   // about 2 x RT_HINT_HALF photons in the bracket
+  const float delta_lo = fminf(0.25f, RT_HINT_LO / (float)(K + 1));   // about RT_HINT_LO + RT_HINT_HI photons in the bracket
+  const float delta_hi = fminf(0.25f, RT_HINT_HI / (float)(K + 1));
   float lo, hi;
-  if (hint * (1.0f + delta) >= r2) {
+  if (hint * (1.0f + delta_hi) >= r2) {
     lo = hi = r2;        // expect at most k photons within the radius (the bracket may not reach beyond it)
   } else {
-    lo = hint * (1.0f - delta);
-    hi = hint * (1.0f + delta);
+    lo = hint * (1.0f - delta_lo);
+    hi = hint * (1.0f + delta_hi);
   }
   Collected C;
   uint32_t gs_dummy = 0; (void)gs_dummy;
@@ -651,7 +666,8 @@ RT_DEV bool photon_estimate_hinted(const DPhotonMap& M, V3 pos, V3 normal, float
   }
   if (hi == r2) {
     all = true;
-  } else if (!(C.n_below <= K && C.n_all >= K + 1 && C.n_all - C.n_below <= RT_SEL)) {
+  } else if (!(C.n_below <= K && C.n_all >= K + 1 && C.n_all - C.n_below <= RT_LIST && K - C.n_below < RT_SEL)) {
+    // (all of the bracket's photons noted, and the (k+1)-th nearest among the RT_SEL smallest of them, which is what gets sorted)
     // what this walk saw seeds the counting walks: the answer lies below hi, or above it
     float grow = C.n_all >= 8 ? 1.3f * (float)(K + 1) / (float)C.n_all : 4.0f;
     hint = -(C.n_all >= K + 1 ? hi : fminf(hi * (grow > 1.25f ? grow : 1.25f), 0.999f * r2));

@@ -1384,14 +1384,27 @@ int photon_ensure_built(PhotonState& ps, rt_context* ctx, const rt_render_params
   int n_batches = 0;
   if (!plights.empty()) {
     uint32_t batch = 1u << 16, cap_batch = 1u << 21;
-    const uint32_t cap = batch * 16;   // deposit records a batch may add (16 per path of the smallest batch) before it is retried smaller
+    uint32_t cap = batch * 16;   // deposit records a batch may add (16 per path of the smallest batch) before it is retried smaller
     // A batch takes as long as its longest path (up to photon_max_bounces closest-hit queries in a row), however few
     // paths it has: the build before this one says how many paths fill the maps, so that one batch does it.  Paths past
     // the point where both maps are full deposit nothing that is kept (first n in emission order), so aiming high is safe.
     // (first up to where the first map was full: past it that map's deposits would only fill the record buffers)
     uint32_t plan[2] = {std::min(ps.paths_needed[0], ps.paths_needed[1]), std::max(ps.paths_needed[0], ps.paths_needed[1])};
     auto planned = [&](uint32_t upto) { return std::min<uint32_t>(cap_batch, (upto + upto / 32 + 4095u) & ~4095u); };
-    if (plan[0] > batch) batch = planned(plan[0]);
+    if (plan[0] > 0) {
+      // ONE batch for both maps where the record buffers can be afforded: the map that fills first goes on depositing (those
+      // records are dropped when the slots are dealt: first n in emission order), about n / paths_needed[w] per path.  Two
+      // batches are two launches as long as their longest paths.
+      const uint32_t one = planned(plan[1]);
+      const double est = (double)one * ((double)n / (double)plan[0]) * 1.25;   // the denser map's deposits, with a margin
+      if (plan[1] <= cap_batch && est < 32.0e6) {
+        batch = one;
+        cap = std::max<uint32_t>(cap, ((uint32_t)est + 4095u) & ~4095u);
+        plan[1] = 0;
+      } else if (plan[0] > batch) {
+        batch = planned(plan[0]);
+      }
+    }
     if (max_b > 255) return fail(ctx, RT_ERR_UNSUPPORTED, "photon_max_bounces must be <= 255");
     Carver cv;
     float4* d_rec[2] = {nullptr, nullptr};
