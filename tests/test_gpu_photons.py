@@ -58,3 +58,33 @@ def test_c4_adaptive_photons_denoise_end_to_end(gpu_renderer):
 
 def test_gather_hints_change_walks_only(gpu_renderer):
     pc.check_gather_hints(gpu_renderer, Scene.load(scene_path("cornell_box.xml")), n_photons=20000, w=240, h=135, spp=4, tol=1e-5)
+
+
+def test_undersized_queues_with_photons_and_soft_shadows():
+    """Every level of a pass appends its shadow groups and its photon lookups to one set of queues, served once after the last
+    level.  With the measured queue sizing shrunk 20x the pass overflows, leaves the accumulator alone and is redone in halves:
+    the frame must equal the one rendered with queues of the measured size (same library, same photon maps; photon frames
+    agree to the order of their float sums), and the work of the overflowed attempts must not be counted."""
+    from raytracer_amd import Renderer
+    scene = Scene.load(scene_path("cornell_box.xml"))
+    p = pc.photon_params(20000, w=192, h=108, spp=4, bounces=3, k=32)
+    p.shadow_min, p.shadow_max = 16, 128
+    p.frame_mem_mb = 1   # the smallest pass size (65536 camera samples): the queues are then sized for the passes of this frame
+    frames, counts, launches = [], [], []
+    for fan_scale in (1.0, 0.05):
+        r = Renderer(0)
+        r.set_option("fan_scale", fan_scale)
+        r.LoadScene(scene)
+        r.BuildPhotonMaps(p)
+        r.counters(enable=True, reset=True)
+        r.profile(enable=True, reset=True)
+        frames.append(r.Render(p))
+        counts.append(r.counters())
+        launches.append(r.profile()["raygen"]["launches"])
+    assert launches[1] > launches[0], "the pass was not split: the test did not reach the overflow path"
+    a, b = frames[0].radiance, frames[1].radiance
+    assert (a[..., 3] == 4).all() and (b[..., 3] == 4).all()
+    rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(a[..., :3]), 1e-3)
+    assert rel.max() <= 1e-4, rel.max()
+    for k in ("rays_primary", "rays_secondary", "paths", "shades", "gathers"):
+        assert counts[0][k] == counts[1][k], (k, counts[0][k], counts[1][k])
