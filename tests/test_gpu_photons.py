@@ -85,6 +85,6 @@ def test_undersized_queues_with_photons_and_soft_shadows():
     a, b = frames[0].radiance, frames[1].radiance
     assert (a[..., 3] == 4).all() and (b[..., 3] == 4).all()
     rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(a[..., :3]), 1e-3)
-    assert rel.max() <= 1e-4, rel.max()
+    assert rel.max() <= 1e-5, rel.max()   # (measured: 3e-7)
     for k in ("rays_primary", "rays_secondary", "paths", "shades", "gathers"):
         assert counts[0][k] == counts[1][k], (k, counts[0][k], counts[1][k])
