@@ -69,7 +69,9 @@
                                // against the 16 rays through the instance BVH (~300 each) a proof may save
 #endif
 #ifndef RT_TLAS_MIN
-#define RT_TLAS_MIN 24   // instances from which the instance BVH replaces the linear table walk
+#define RT_TLAS_MIN 80   // instances from which the instance BVH replaces the linear table walk.  24 until the first trace phase was
+                         // fused with shading (table walks only): finalProject.xml, 70 instances, raygen + first phase + shading of
+                         // their rays 4.09 ms with the BVH, 3.51 ms with the table; ~0.023 ms per instance puts the crossover near 95
 #endif
 #ifndef RT_SOFT_CHUNK
 #define RT_SOFT_CHUNK 32   // soft-shadow samples per launch of the second sample phase when the scene has meshes (run_pass)
