@@ -383,7 +383,9 @@ int rt_profile_get(rt_context* ctx, rt_profile* out);
  * (instances up to which those proofs walk the instance table; beyond it the instance BVH), "shadow_tlas_min" (instances from
  * which shadow rays walk the instance BVH; next commit), "fuse" (1: first trace phase and shading of the rays it finishes in
  * one kernel), "shadow_hints" (soft-shadow rays head for the triangle that blocked their group's previous ray first: 1 on,
- * 0 off, -1 — the default — by the depth of the scene's mesh trees; the same frame either way).  Their initial values
+ * 0 off, -1 — the default — by the depth of the scene's mesh trees; the same frame either way), "restart_min_depth" (mesh
+ * trees at least this deep let such a walk begin in the subtree around its hint and take the rest of the tree only if that
+ * holds no occluder; default 19, next commit; the same frame either way).  Their initial values
  * come from the environment variables RT_TLAS_MIN / RT_GATHER_HINTS / RT_FRAME_GB / RT_TEST_FAN_SCALE / RT_TIMING /
  * RT_SOFT_CLEAR / RT_SHADOW_HINTS, read once by rt_context_create. */
 int rt_set_option(rt_context* ctx, const char* name, double value);

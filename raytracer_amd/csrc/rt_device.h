@@ -60,7 +60,8 @@ struct DMesh {
   uint32_t node_base;   // float4 index of this mesh's first 64-byte BVH node in DScene::bvh
   uint32_t tri_base;    // float4 index of this mesh's first 48-byte triangle slot in DScene::tris
   uint32_t shade_base;  // index of this mesh's first 80-byte face record in DScene::shade
-  uint32_t pad_[3];
+  uint32_t anc_base, anc_blocks;   // as DMeshInst
+  uint32_t pad_[1];
   uint32_t root_ref;    // child reference of the root (leaf bit | first_slot<<3 | count, or internal node index)
   uint32_t has_uvw;
   float bounds[6];      // root box: min xyz, max xyz
@@ -75,7 +76,8 @@ struct DMeshInst {      // what the second-phase walk needs to enter a mesh inst
   int32_t xf_off;
   uint32_t root_ref;
   uint32_t node_base, tri_base;
-  uint32_t pad_[2];
+  uint32_t anc_base;    // this mesh's first entry in DScene::bvh_anc (RT_NONE: none) ...
+  uint32_t anc_blocks;  // ... and how many it has
 };
 
 struct DTexColor { float v[3]; int32_t map; };
@@ -114,6 +116,7 @@ struct DScene {
   const float* xf;      // transform chains, see DInstance::xf_off
   const DMesh* meshes;
   const float4* bvh;
+  const uint32_t* bvh_anc;   // per mesh and block of 2^RT_ANC_SHIFT triangle slots: the smallest inner node whose slots hold the block
   const float4* tris;
   const float4* shade;  // per face, 5 float4: the three vertex normals and texture coordinates, indices resolved at commit
                         // (n0 | t0.x) (n1 | t0.y) (n2 | t0.z) (t1 | t2.x) (t2.y t2.z - -)
@@ -1424,7 +1427,15 @@ struct MeshWalk {
   uint32_t minst;      // ... and its position in DScene::minst_rec
   uint32_t hint;       // any-hit walks (k_shadow_mesh): the triangle slot to head for first while `onpath`
   bool onpath;         // the walk stands on the path from the root to the hinted slot
+  uint32_t root;       // the instance's root reference
+  uint32_t skip;       // a subtree already searched (RT_NOREF: none), see "around the hint first" in k_shadow_mesh
+  bool restart;        // the walk began at `skip` and has the rest of the tree still to do
+  uint32_t anc_base, anc_blocks;
 };
+#ifndef RT_ANC_SHIFT
+#define RT_ANC_SHIFT 10
+#endif
+// RT_ANC_SHIFT:   // DScene::bvh_anc has one entry per 2^RT_ANC_SHIFT triangle slots of a mesh
 #define RT_NOREF 0xFFFFFFFFu
 RT_DEV bool ref_is_node(uint32_t r) { return !(r & RT_LEAF); }                  // (RT_NOREF has the leaf bit)
 RT_DEV bool ref_is_leaf(uint32_t r) { return (r & RT_LEAF) && r != RT_NOREF; }
@@ -1442,6 +1453,8 @@ RT_DEV void mesh_walk_enter(const DScene& S, const float4* cand, uint32_t ci, Me
   W.fast = inv_is_finite(W.inv);
   W.next = __float_as_uint(c1.w);
   W.cur = R.root_ref; W.pend = 0; W.sp = 0; W.inst = R.inst;
+  W.root = R.root_ref; W.skip = RT_NOREF; W.restart = false;
+  W.anc_base = R.anc_base; W.anc_blocks = R.anc_blocks;
   W.minst = __float_as_uint(c0.w);
   W.node_base = R.node_base; W.tri_base = R.tri_base;
 }
@@ -1484,6 +1497,8 @@ RT_DEV void mesh_walk_node(MeshWalk& W, float4 n0, float4 n1, float4 n2, float4 
   uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
   bool left_first = ORDERED ? (tl <= tr) : true;
   if (HINT) {
+    hl = hl && cl != W.skip;   // (the subtree the walk began with: found empty of occluders already)
+    hr = hr && cr != W.skip;
     const bool hint_left = W.hint < __float_as_uint(n3.z);
     if (W.onpath) left_first = hint_left;
     W.onpath = W.onpath && (hint_left ? hl : hr);

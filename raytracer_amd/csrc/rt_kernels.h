@@ -457,6 +457,7 @@ RT_KERNEL_W(RT_MESH_WAVES, k_trace_mesh, DScene S, PassP P, FrameBufs F, RayQ Q,
   W.p = W.d = W.inv = v3(0, 0, 0);
   W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
   W.hint = 0; W.onpath = false; W.minst = RT_NONE;
+  W.root = RT_NOREF; W.skip = RT_NOREF; W.restart = false; W.anc_base = RT_NONE; W.anc_blocks = 0;
   MeshHit L;
   L.t = RT_BIG; L.u = L.v = 0; L.key = 0; L.face = 0;
   bool lfound = false;
@@ -1327,12 +1328,21 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
   W.p = W.d = W.inv = v3(0, 0, 0);
   W.cur = RT_NOREF; W.pend = 0; W.node_base = W.tri_base = 0; W.sp = 0; W.next = RT_NONE; W.inst = -1; W.fast = true;
   W.hint = 0; W.onpath = false; W.minst = RT_NONE;
+  W.root = RT_NOREF; W.skip = RT_NOREF; W.restart = false; W.anc_base = RT_NONE; W.anc_blocks = 0;
 #ifdef RT_SM_STATS   // developer build: node steps of the rays that end lit / occluded (scripts/dev/sm_stats.sh)
   uint32_t my_steps = 0; unsigned long long st_lit = 0, st_occ = 0, n_lit = 0, n_occ = 0;
 #endif
   for (;;) {  // one wave-wide step per iteration, as in k_trace_mesh
     if (state == RT_ST_WALK && W.pend == 0 && ref_is_leaf(W.cur)) { W.pend = W.cur; W.cur = walk_pop(W, stk, stride); W.onpath = false; }
-    if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) state = RT_ST_NEXT;
+    if (state == RT_ST_WALK && W.cur == RT_NOREF && W.pend == 0) {
+      if (HINT && W.restart) {   // nothing in the subtree around the hint: now the whole tree, without that subtree
+        W.restart = false;
+        W.cur = W.root;
+        W.onpath = true;
+      } else {
+        state = RT_ST_NEXT;
+      }
+    }
     const bool walking = state == RT_ST_WALK;
     const bool at_node = walking && ref_is_node(W.cur);
     const uint32_t n_walk = count_lanes(walking), n_node = count_lanes(at_node), n_pend = count_lanes(walking && W.pend != 0);
@@ -1376,6 +1386,21 @@ RT_KERNEL_W(RT_SHADOW_MESH_WAVES, k_shadow_mesh, DScene S, PassP P, FrameBufs F,
         mesh_walk_enter<CNT>(S, MQ.cand, enter, W, cnt);
         W.hint = hint_slot;
         W.onpath = HINT && W.minst == hint_minst;
+        if (HINT && W.onpath && W.fast && (hint_slot >> RT_ANC_SHIFT) < W.anc_blocks) {
+// Around the hint first.  59 % of the occluded rays of C5 are blocked within 64 triangle slots of their hint, 72 %
+          // within 256, 81 % within 1024 — and a walk from the root, even steered, spends ~22 of its 33 node steps on the way down.
+          // The walk begins at the smallest inner node that holds the hint's block of 1024 slots; only if nothing occludes the ray
+          // there does it start again at the root (skipping that subtree): 33 -> 22 node steps per occluded ray, lit rays unchanged.
+          // The answer does not change: the slab test is monotone in the box — every quantity it compares moves one way when the
+          // box grows, in floating point too — and a node's box holds its children's (checked per mesh at commit), so a ray that
+          // enters a box enters every ancestor's as well: a triangle tested here is one the walk from the root tests too.  (Rays
+          // with a non-finite reciprocal direction take the literal NaN-aware form of the test, which is not monotone: they
+          // start at the root.)  Blocks of 64 / 256 / 1024 / 4096 slots: 561 / 545 / 544 / 553 ms per C5 step against 587; a walk
+          // that starts at the 64-slot block and climbs parent by parent through the root (every node at most once) takes fewer
+          // node steps still (19) and more time (661 ms): near the leaves it tests sibling leaves that a box higher up prunes.
+          const uint32_t a = S.bvh_anc[W.anc_base + (hint_slot >> RT_ANC_SHIFT)];
+          if (a != W.root) { W.cur = a; W.skip = a; W.restart = true; }
+        }
         state = RT_ST_WALK;
       }
       continue;

@@ -129,6 +129,8 @@ struct Options {
                                    //                                  0: the separate k_raygen_trace / k_trace_closest / k_shade launches
   double shadow_hints = -1;        // "shadow_hints" RT_SHADOW_HINTS   soft-shadow mesh walks head for the previous ray's occluder first: 1 on, 0 off,
                                    //                                  -1 by the depth of the scene's mesh trees (>= RT_SHADOW_HINT_DEPTH)
+  double restart_min_depth = RT_SHADOW_HINT_DEPTH;   // "restart_min_depth"  mesh trees at least this deep get the table that lets a hinted shadow walk
+                                                     //                      start around its hint (k_shadow_mesh); takes effect at the next rt_scene_commit
   double summary_mapped = 1;       // "summary_mapped" RT_SUMMARY_MAPPED  1: the per-pass summary is written into pinned host memory by the kernel itself
   double cone_max_inst = RT_CONE_MAX_INST;   // "cone_max_inst"  instances up to which the soft-shadow proofs walk the instance table; beyond it
                                              //                  (with an instance BVH) every group's cone walks the BVH (tests force both)
@@ -320,6 +322,8 @@ struct MeshConv {
   size_t visited = 0;
   int max_depth = 0;
   std::string err;
+  std::vector<uint32_t> anc;   // per block of 2^RT_ANC_SHIFT slots: the smallest inner node whose slot range holds the block (DScene::bvh_anc)
+  bool nested = true;          // every node's box holds its children's boxes (what starting a walk below the root relies on)
   MeshConv(const rt_mesh& mm, std::vector<float4>& n, std::vector<float4>& t) : m(mm), nodes(n), tris(t) {
     node_base = n.size();
     tri_base = t.size();
@@ -361,9 +365,17 @@ struct MeshConv {
     const rt_bvh_node& l = m.bvh[n.a];
     const rt_bvh_node& r = m.bvh[n.b];
     uint32_t lref, rref;
+    const uint32_t first_slot = n_slots;
     if (!convert(n.a, depth + 1, lref)) return false;
     const uint32_t right_first = n_slots;   // the children cover consecutive slot ranges: the right one's begins here (occluder hints)
     if (!convert(n.b, depth + 1, rref)) return false;
+    for (int k = 0; k < 3; k++)
+      if (!(l.bmin[k] >= n.bmin[k] && l.bmax[k] <= n.bmax[k] && r.bmin[k] >= n.bmin[k] && r.bmax[k] <= n.bmax[k])) nested = false;
+    // blocks that lie in this node's slot range and in neither child's alone (the children came first and took theirs)
+    for (uint32_t b = (first_slot + (1u << RT_ANC_SHIFT) - 1) >> RT_ANC_SHIFT; ((b + 1) << RT_ANC_SHIFT) <= n_slots; b++) {
+      if (anc.size() <= b) anc.resize(b + 1, RT_NONE);
+      if (anc[b] == RT_NONE) anc[b] = me;
+    }
     // per axis: (left min, right min, left max, right max) — the two children's slab tests run as packed FP32 pairs
     nodes[at + 0] = make_float4(l.bmin[0], r.bmin[0], l.bmax[0], r.bmax[0]);
     nodes[at + 1] = make_float4(l.bmin[1], r.bmin[1], l.bmax[1], r.bmax[1]);
@@ -652,6 +664,7 @@ int rt_set_option(rt_context* ctx, const char* name, double value) {
   else if (n == "soft_clear") ctx->opt.soft_clear = value;
   else if (n == "cone_max_inst") ctx->opt.cone_max_inst = value;
   else if (n == "fuse") ctx->opt.fuse = value;
+  else if (n == "restart_min_depth") ctx->opt.restart_min_depth = value;
   else if (n == "shadow_hints") ctx->opt.shadow_hints = value;
   else if (n == "shadow_tlas_min") ctx->opt.shadow_tlas_min = value;   // takes effect at the next rt_scene_commit
   else return fail(ctx, RT_ERR_INVALID, "unknown option: " + n);
@@ -796,6 +809,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   std::vector<float4> bvh, tris;
   std::vector<float4> shade;   // DScene::shade
   std::vector<float4> face_pos(1);   // DScene::face_pos (meshes with texture coordinates only)
+  std::vector<uint32_t> bvh_anc(1);  // DScene::bvh_anc
   std::vector<uint32_t> face_pos_base(sc->n_meshes, RT_NONE);
   for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
     const rt_mesh& m = sc->meshes[mi];
@@ -807,6 +821,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     }
     DMesh& D = meshes[mi];
     std::memset(&D, 0, sizeof D);
+    D.anc_base = RT_NONE;   // (meshes whose tree is built on the device: walks start at the root)
     if (!m.bvh) continue;
     MeshConv cv(m, bvh, tris);
     uint32_t root;
@@ -818,6 +833,14 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     const rt_bvh_node& r = m.bvh[0];
     for (int k = 0; k < 3; k++) { D.bounds[k] = r.bmin[k]; D.bounds[3 + k] = r.bmax[k]; }
     minfo[mi].n_nodes = cv.n_internal; minfo[mi].n_slots = cv.n_slots;
+    if (cv.nested && !(root & RT_LEAF) && cv.n_slots > 0 && cv.max_depth >= (int)ctx->opt.restart_min_depth) {
+      // the last block may be partial, and a block that straddles the two halves of the root is the root's: both say "start at the root"
+      cv.anc.resize(((size_t)cv.n_slots + (1u << RT_ANC_SHIFT) - 1) >> RT_ANC_SHIFT, RT_NONE);
+      for (auto& a : cv.anc) if (a == RT_NONE) a = root;
+      D.anc_base = (uint32_t)bvh_anc.size();
+      D.anc_blocks = (uint32_t)cv.anc.size();
+      bvh_anc.insert(bvh_anc.end(), cv.anc.begin(), cv.anc.end());
+    }
   }
   size_t dev_nodes = 0, dev_slots = 0;   // float4s behind the converted part
   for (uint32_t mi = 0; mi < sc->n_meshes; mi++) {
@@ -985,6 +1008,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
   if ((rc = upload(ctx, ctx->scene_mem, meshes, &D.meshes))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, shade, &D.shade))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, face_pos, &D.face_pos))) return rc;
+  if ((rc = upload(ctx, ctx->scene_mem, bvh_anc, &D.bvh_anc))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, mtls, &D.materials))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, tms, &D.texmaps))) return rc;
   if ((rc = upload(ctx, ctx->scene_mem, imgs, &D.images))) return rc;
@@ -1005,6 +1029,7 @@ int rt_scene_commit(rt_context* ctx, const rt_scene_desc* sc) {
     for (int c = 0; c < 6; c++) R.bounds[c] = M.bounds[c];
     R.inst = minst[k]; R.depth = I.depth; R.xf_off = I.xf_off;
     R.root_ref = M.root_ref; R.node_base = M.node_base; R.tri_base = M.tri_base;
+    R.anc_base = M.anc_base; R.anc_blocks = M.anc_blocks;
   }
   if ((rc = upload(ctx, ctx->scene_mem, minst_rec, &D.minst_rec))) return rc;
   D.n_minst = (int32_t)minst.size();

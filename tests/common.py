@@ -593,8 +593,9 @@ def check_shadow_hints(r, scene, w, h, spp=1, tol=5e-5, device_bvh=False):
     both equal the oracle's.  Run on the stress scene's shape (rays start on the mesh that shadows them)."""
     import oracle_ffi
     frames = []
-    for on in (0, 1):
-        r.set_option("shadow_hints", on)
+    for on in (0, 1, 2):   # off, on (walks from the root, steered), on + walks that start around their hint (forced for this small tree)
+        r.set_option("shadow_hints", min(on, 1))
+        r.set_option("restart_min_depth", 0 if on == 2 else 99)
         try:
             r.LoadScene(scene)
             p = params(w, h, spp=spp, jitter=1, bounces=1)
@@ -604,13 +605,15 @@ def check_shadow_hints(r, scene, w, h, spp=1, tol=5e-5, device_bvh=False):
             r.counters(enable=False)
         finally:
             r.set_option("shadow_hints", -1)
-    a, b = frames
-    assert np.array_equal(a.hit_node, b.hit_node)
-    assert np.abs(a.radiance[..., :3] - b.radiance[..., :3]).max() <= 1e-5, np.abs(a.radiance[..., :3] - b.radiance[..., :3]).max()
+            r.set_option("restart_min_depth", 19)
+    a, b, b2 = frames
+    for f in (b, b2):
+        assert np.array_equal(a.hit_node, f.hit_node)
+        assert np.abs(a.radiance[..., :3] - f.radiance[..., :3]).max() <= 1e-5, np.abs(a.radiance[..., :3] - f.radiance[..., :3]).max()
     c = oracle_ffi.OracleScene(scene.with_bvh({0: r.GetMeshBVH(0)}) if device_bvh else scene).render(params(w, h, spp=spp, jitter=1, bounces=1))
     assert np.abs(b.radiance[..., :3] - c.radiance[..., :3]).max() <= tol, np.abs(b.radiance[..., :3] - c.radiance[..., :3]).max()
     shadowed = (c.radiance[..., :3].sum(axis=-1) < 0.5 * np.median(c.radiance[..., :3].sum(axis=-1))).mean()
-    print(f"shadow hints: node visits {a.node_visits} -> {b.node_visits} ({b.node_visits / a.node_visits:.3f}), dark pixels {shadowed:.2f}")
+    print(f"shadow hints: node visits {a.node_visits} -> {b.node_visits} ({b.node_visits / a.node_visits:.3f}), around the hint first {b2.node_visits}, dark pixels {shadowed:.2f}")
     return a.node_visits, b.node_visits
 
 
